@@ -1,0 +1,74 @@
+// api.cpp - error state, device discovery, pinned host memory and stream-ordered copies of the
+// C ABI (include/dcvc_amd.h).
+#include <cstdarg>
+#include <cstdio>
+
+#include "common.hpp"
+
+namespace dcvc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace dcvc
+
+extern "C" {
+
+int dcvc_abi_version(void) { return DCVC_ABI_VERSION; }
+
+const char* dcvc_last_error(void) { return dcvc::g_err; }
+
+int dcvc_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        dcvc::set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return dcvc::E_HIP;
+    }
+    return n;
+}
+
+void* dcvc_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
+        dcvc::set_error("hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void dcvc_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+int dcvc_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream)
+{
+    DCVC_REQUIRE(dst_host && src_dev, "dcvc_memcpy_d2h: null pointer");
+    DCVC_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
+
+int dcvc_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream)
+{
+    DCVC_REQUIRE(dst_dev && src_host, "dcvc_memcpy_h2d: null pointer");
+    DCVC_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+int dcvc_stream_sync(void* stream)
+{
+    DCVC_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,764 @@
+// dcvc_elem.hip - HBM-bound elementwise / layout / entropy-glue kernels of the DCVC-RT path.
+//  (1) pipeline forms on HWC tensors with the checkerboard masks computed from (h, w, c);
+//  (2) the flat NCHW forms of the reference's operator module (inference_extensions_cuda,
+//      kernel.cu:56-1004) with the reference's own signatures, for the operator seam.
+// All arithmetic is fp32 with the shared deterministic math of include/dcvc_math.h; storage is
+// _Float16 or float.
+#include "common.hpp"
+#include "gemm_core.hpp"
+
+namespace {
+
+constexpr int EB = 256;   // threads per block for 1-D kernels
+
+inline int nblocks(int64_t n) { return (int)((n + EB - 1) / EB); }
+
+template <typename T>
+__device__ __forceinline__ float ld(const T* p, int64_t i)
+{
+    return (float)p[i];
+}
+template <typename T>
+__device__ __forceinline__ void st(T* p, int64_t i, float v)
+{
+    p[i] = (T)v;
+}
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi)
+{
+    v = v < lo ? lo : v;
+    return v > hi ? hi : v;
+}
+
+constexpr float kScaleMin = 0.11f, kScaleMax = 16.0f;
+// log(0.11) and 127 / (log(16) - log(0.11)) rounded to float exactly as the reference's python
+// floats are when passed into torch fp32 expressions (entropy_models.py:235-238)
+constexpr float kLogScaleMin = -2.2072749131897207f;
+constexpr float kLogStepRecip = 25.50270635855404f;
+
+// active channel group for checkerboard step `step` at pixel (h, w): see common_model.py:99-131
+__device__ __forceinline__ int active_group(int n_groups, int step, int h, int w)
+{
+    if (n_groups == 2) return ((h + w) & 1) ^ (step & 1);
+    const int pos = ((h & 1) << 1) | (w & 1);
+    const int x = (step == 0) ? 0 : (step == 1) ? 3 : (step == 2) ? 2 : 1;
+    return pos ^ x;
+}
+
+// ------------------------------------------------------------------ layout kernels
+template <typename T>
+__global__ void unshuffle8_kernel(const T* x, int C, int H, int W, T* out, int64_t ldo)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= (int64_t)C * H * W) return;
+    const int xw = (int)(i % W), y = (int)((i / W) % H), c = (int)(i / ((int64_t)W * H));
+    const int W8 = W / 8;
+    out[((int64_t)(y >> 3) * W8 + (xw >> 3)) * ldo + c * 64 + (y & 7) * 8 + (xw & 7)] = x[i];
+}
+
+template <typename T>
+__global__ void shuffle8_kernel(const T* x, int64_t ldx, const float* bias, int C, int H, int W, int do_clamp, T* out)
+{
+    const int HO = H * 8, WO = W * 8;
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= (int64_t)C * HO * WO) return;
+    const int xw = (int)(i % WO), y = (int)((i / WO) % HO), c = (int)(i / ((int64_t)WO * HO));
+    const int ch = c * 64 + (y & 7) * 8 + (xw & 7);
+    float v = ld(x, ((int64_t)(y >> 3) * W + (xw >> 3)) * ldx + ch);
+    if (bias) v = v + bias[ch];
+    if (do_clamp) v = clampf(v, 0.f, 1.f);
+    st(out, i, v);
+}
+
+template <typename T>
+__global__ void replicate_pad_hwc_kernel(const T* x, int64_t ldx, int H, int W, int C, int HO, int WO, T* out, int64_t ldo)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= (int64_t)HO * WO * C) return;
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int xw = (int)(p % WO), y = (int)(p / WO);
+    const int sy = y < H ? y : H - 1, sx = xw < W ? xw : W - 1;
+    out[p * ldo + c] = x[((int64_t)sy * W + sx) * ldx + c];
+}
+
+template <typename T>
+__global__ void scale_channels_kernel(const T* x, int64_t ldx, const float* q, int64_t P, int C, T* out, int64_t ldo)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= P * C) return;
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    st(out, p * ldo + c, ld(x, p * ldx + c) * q[c]);
+}
+
+template <typename T>
+__global__ void copy_channels_kernel(const T* x, int64_t ldx, int64_t P, int C, T* out, int64_t ldo)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= P * C) return;
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    out[p * ldo + c] = x[p * ldx + c];
+}
+
+template <typename T>
+__global__ void crop_hwc_kernel(const T* x, int64_t ldx, int W, int H2, int W2, int C, T* out, int64_t ldo)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= (int64_t)H2 * W2 * C) return;
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int xw = (int)(p % W2), y = (int)(p / W2);
+    out[p * ldo + c] = x[((int64_t)y * W + xw) * ldx + c];
+}
+
+template <typename T>
+__global__ void nchw_to_hwc_kernel(const T* x, int C, int64_t HW, T* out, int64_t ldo)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= HW * C) return;
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    out[p * ldo + c] = x[(int64_t)c * HW + p];
+}
+
+template <typename T>
+__global__ void hwc_to_nchw_kernel(const T* x, int64_t ldx, int C, int64_t HW, T* out)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= HW * C) return;
+    const int64_t p = i % HW;
+    const int c = (int)(i / HW);
+    out[i] = x[p * ldx + c];
+}
+
+// ------------------------------------------------------------------ z quantiser
+template <typename T>
+__global__ void round_z_kernel(T* z, int64_t ldz, int64_t HW, int C, int8_t* z_chw)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= HW * C) return;
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const float v = clampf(dcvc_roundf(ld(z, p * ldz + c)), -128.f, 127.f);
+    st(z, p * ldz + c, v);
+    z_chw[(int64_t)c * HW + p] = (int8_t)v;
+}
+
+template <typename T>
+__global__ void z_from_int8_kernel(const int8_t* z_chw, int64_t HW, int C, T* out, int64_t ldo)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= HW * C) return;
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    st(out, p * ldo + c, (float)z_chw[(int64_t)c * HW + p]);
+}
+
+// ------------------------------------------------------------------ checkerboard prior loop
+// One block = 64 consecutive pixels x all collapsed channels.  Phase 1 walks (pixel, channel) with
+// the channel fastest (coalesced HWC reads / y_hat writes); the packed symbols go through LDS so
+// phase 2 can write them pixel-fastest in the reference's CHW order.
+constexpr int PT = 64;
+
+struct PriorEncArgs {
+    int n_groups, step, q_mode;
+    const void* y;
+    int64_t ldy;
+    const void* qsrc;
+    int64_t ldq;
+    const void* scales;
+    int64_t lds;
+    const void* means;
+    int64_t ldm;
+    int H, W, C;
+    float thres;
+    const void* yhat_in;
+    int64_t ldhi;
+    void* yhat_out;
+    int64_t ldho;
+    int16_t* packed;
+};
+
+template <typename T>
+__global__ __launch_bounds__(EB) void prior_enc_kernel(PriorEncArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int16_t* sp = reinterpret_cast<int16_t*>(smem);   // [Cg][PT]
+    const int Cg = a.C / a.n_groups;
+    const int64_t HW = (int64_t)a.H * a.W;
+    const int64_t p0 = (int64_t)blockIdx.x * PT;
+    const T* y = (const T*)a.y;
+    const T* qs = (const T*)a.qsrc;
+    const T* sc = (const T*)a.scales;
+    const T* mu = (const T*)a.means;
+    const T* hin = (const T*)a.yhat_in;
+    T* hout = (T*)a.yhat_out;
+    for (int it = threadIdx.x; it < PT * Cg; it += EB) {
+        const int pl = it / Cg, cc = it - pl * Cg;
+        const int64_t p = p0 + pl;
+        if (p >= HW) continue;
+        const int h = (int)(p / a.W), w = (int)(p - (int64_t)h * a.W);
+        const int ga = active_group(a.n_groups, a.step, h, w);
+        int16_t packed = 0;
+        for (int g = 0; g < a.n_groups; ++g) {
+            const int ch = cc + g * Cg;
+            const float prev = a.step == 0 ? 0.f : ld(hin, p * a.ldhi + ch);
+            if (g != ga) {
+                st(hout, p * a.ldho + ch, prev);
+                continue;
+            }
+            float qe;
+            if (a.q_mode == 0) {
+                float qd = ld(qs, p * a.ldq + ch);
+                qd = qd < 0.5f ? 0.5f : qd;
+                qe = 1.0f / qd;
+            } else {
+                qe = dcvc_sigmoidf(ld(qs, p * a.ldq)) * 1.5f + 0.5f;
+            }
+            const float yq = ld(y, p * a.ldy + ch) * qe;
+            const float s = ld(sc, p * a.lds + ch), m = ld(mu, p * a.ldm + ch);
+            float v = dcvc_roundf(yq - m);
+            const bool use_thres = a.thres >= 0.f;
+            if (use_thres && !(s > a.thres)) v = v * 0.f;
+            v = clampf(v, -128.f, 127.f);
+            // T-rounded like the reference, whose y_hat_k tensors are stored in the model dtype
+            const float yh = (float)(T)(v + m);
+            st(hout, p * a.ldho + ch, a.step == 0 ? yh : prev + yh);
+            const float scl = clampf(s, kScaleMin, kScaleMax);
+            const bool keep = !use_thres || (scl > a.thres);
+            const int idx = keep ? (int)dcvc_scale_to_index(scl, kScaleMin, kScaleMax, kLogScaleMin, kLogStepRecip) : 0xFF;
+            packed = (int16_t)((int)v * 256 + idx);
+        }
+        sp[cc * PT + pl] = packed;
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < PT * Cg; it += EB) {
+        const int cc = it / PT, pl = it - cc * PT;
+        const int64_t p = p0 + pl;
+        if (p < HW) a.packed[(int64_t)cc * HW + p] = sp[cc * PT + pl];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(EB) void prior_dec_index_kernel(int n_groups, int step, const T* sc, int64_t lds, int H, int W,
+                                                            int C, float thres, uint8_t* idx_chw)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint8_t* sp = reinterpret_cast<uint8_t*>(smem);   // [Cg][PT]
+    const int Cg = C / n_groups;
+    const int64_t HW = (int64_t)H * W;
+    const int64_t p0 = (int64_t)blockIdx.x * PT;
+    for (int it = threadIdx.x; it < PT * Cg; it += EB) {
+        const int pl = it / Cg, cc = it - pl * Cg;
+        const int64_t p = p0 + pl;
+        if (p >= HW) continue;
+        const int h = (int)(p / W), w = (int)(p - (int64_t)h * W);
+        const int ch = cc + active_group(n_groups, step, h, w) * Cg;
+        const float scl = clampf(ld(sc, p * lds + ch), kScaleMin, kScaleMax);
+        const bool keep = thres < 0.f || scl > thres;
+        sp[cc * PT + pl] = keep ? dcvc_scale_to_index(scl, kScaleMin, kScaleMax, kLogScaleMin, kLogStepRecip) : (uint8_t)0xFF;
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < PT * Cg; it += EB) {
+        const int cc = it / PT, pl = it - cc * PT;
+        const int64_t p = p0 + pl;
+        if (p < HW) idx_chw[(int64_t)cc * HW + p] = sp[cc * PT + pl];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(EB) void prior_dec_restore_kernel(int n_groups, int step, const int8_t* sym_chw, const T* mu,
+                                                              int64_t ldm, int H, int W, int C, const T* hin,
+                                                              int64_t ldhi, T* hout, int64_t ldho)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int8_t* sp = reinterpret_cast<int8_t*>(smem);   // [Cg][PT]
+    const int Cg = C / n_groups;
+    const int64_t HW = (int64_t)H * W;
+    const int64_t p0 = (int64_t)blockIdx.x * PT;
+    for (int it = threadIdx.x; it < PT * Cg; it += EB) {
+        const int cc = it / PT, pl = it - cc * PT;
+        const int64_t p = p0 + pl;
+        sp[cc * PT + pl] = p < HW ? sym_chw[(int64_t)cc * HW + p] : (int8_t)0;
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < PT * Cg; it += EB) {
+        const int pl = it / Cg, cc = it - pl * Cg;
+        const int64_t p = p0 + pl;
+        if (p >= HW) continue;
+        const int h = (int)(p / W), w = (int)(p - (int64_t)h * W);
+        const int ga = active_group(n_groups, step, h, w);
+        for (int g = 0; g < n_groups; ++g) {
+            const int ch = cc + g * Cg;
+            const float prev = step == 0 ? 0.f : ld(hin, p * ldhi + ch);
+            if (g != ga) {
+                st(hout, p * ldho + ch, prev);
+                continue;
+            }
+            const float yh = (float)(T)((float)sp[cc * PT + pl] + ld(mu, p * ldm + ch));
+            st(hout, p * ldho + ch, step == 0 ? yh : prev + yh);
+        }
+    }
+}
+
+template <typename T>
+__global__ void prior_finish_kernel(int q_mode, T* yh, int64_t ldh, const T* qs, int64_t ldq, int64_t HW, int C)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= HW * C) return;
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    float q;
+    if (q_mode == 0) {
+        q = ld(qs, p * ldq + c);
+        q = q < 0.5f ? 0.5f : q;
+    } else {
+        q = dcvc_sigmoidf(ld(qs, p * ldq + 1)) * 1.5f + 0.5f;
+    }
+    st(yh, p * ldh + c, ld(yh, p * ldh + c) * q);
+}
+
+// ------------------------------------------------------------------ operator-module (flat) kernels
+template <typename T>
+__global__ void op_process_with_mask_kernel(const T* y, const T* sc, const T* mu, const T* mask, float thres, T* y_res,
+                                            T* y_q, T* y_hat, T* s_hat, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= n) return;
+    const float mk = ld(mask, i);
+    const float sh = ld(sc, i) * mk, mh = ld(mu, i) * mk;
+    const float yr = (ld(y, i) - mh) * mk;
+    float q = dcvc_roundf(yr);
+    if (thres >= 0.f) q = q * (sh > thres ? 1.f : 0.f);
+    q = clampf(q, -128.f, 127.f);
+    st(y_res, i, yr);
+    st(y_q, i, q);
+    st(y_hat, i, q + mh);
+    st(s_hat, i, sh);
+}
+
+template <typename T>
+__global__ void op_combine_2x_kernel(T* out, const T* x, const T* mask, int64_t hn)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= hn) return;
+    st(out, i, ld(x, i) * ld(mask, i) + ld(x, i + hn) * ld(mask, i + hn));
+}
+
+template <typename T>
+__global__ void op_restore_kernel(T* out, const T* y, const T* mu, const T* mask, int64_t gn, int groups)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= gn) return;
+    const float v = ld(y, i);
+    for (int g = 0; g < groups; ++g) st(out, i + g * gn, (v + ld(mu, i + g * gn)) * ld(mask, i + g * gn));
+}
+
+template <typename T>
+__global__ void op_build_index_kernel(int16_t* out_enc, uint8_t* out_dec, uint8_t* cond, const T* sym, const T* sc,
+                                      float smin, float smax, float lmin, float lrec, float thres, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= n) return;
+    const float s = clampf(ld(sc, i), smin, smax);
+    const int idx = dcvc_scale_to_index(s, smin, smax, lmin, lrec);
+    if (out_dec) out_dec[i] = (uint8_t)idx;
+    if (out_enc) out_enc[i] = (int16_t)((int)ld(sym, i) * 256 + idx);
+    if (cond) cond[i] = s > thres ? 1 : 0;
+}
+
+template <typename T>
+__global__ void op_round_int8_kernel(T* z, int8_t* z8, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= n) return;
+    const float v = clampf(dcvc_roundf(ld(z, i)), -128.f, 127.f);
+    st(z, i, v);
+    z8[i] = (int8_t)v;
+}
+
+template <typename T>
+__global__ void op_clamp_recip_kernel(const T* q, T* y, float min_val, T* q_out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= n) return;
+    float qv = ld(q, i);
+    qv = qv < min_val ? min_val : qv;
+    st(q_out, i, qv);
+    st(y, i, ld(y, i) * (1.0f / qv));
+}
+
+template <typename T>
+__global__ void op_add_mul_kernel(T* x0, const T* x1, const T* q, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= n) return;
+    st(x0, i, (ld(x0, i) + ld(x1, i)) * ld(q, i));
+}
+
+template <typename T>
+__global__ void op_bias_quant_kernel(T* x, const T* bias, const T* q, int C, int64_t HW)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= HW * C) return;
+    const int c = (int)(i / HW);
+    st(x, i, (ld(x, i) + ld(bias, c)) * ld(q, c));
+}
+
+template <typename T>
+__global__ void op_ps8_kernel(T* out, const T* x, const T* bias, int C, int H, int W, int do_clamp)
+{   // x: NCHW [C][H][W], out: [C/64][8H][8W]
+    const int HO = H * 8, WO = W * 8, CO = C / 64;
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= (int64_t)CO * HO * WO) return;
+    const int xw = (int)(i % WO), y = (int)((i / WO) % HO), c = (int)(i / ((int64_t)WO * HO));
+    const int ch = c * 64 + (y & 7) * 8 + (xw & 7);
+    float v = ld(x, ((int64_t)ch * H + (y >> 3)) * W + (xw >> 3)) + ld(bias, ch);
+    if (do_clamp) v = clampf(v, 0.f, 1.f);
+    st(out, i, v);
+}
+
+template <typename T>
+__global__ void op_replicate_pad_kernel(const T* x, int C, int H, int W, int HO, int WO, T* out)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= (int64_t)C * HO * WO) return;
+    const int xw = (int)(i % WO), y = (int)((i / WO) % HO), c = (int)(i / ((int64_t)WO * HO));
+    const int sy = y < H ? y : H - 1, sx = xw < W ? xw : W - 1;
+    out[i] = x[((int64_t)c * H + sy) * W + sx];
+}
+
+template <typename T>
+__global__ void op_bias_wsilu_dw_kernel(const T* x, const T* w, const T* bias, int C, int H, int W, T* out)
+{   // NCHW, w: [C][3][3]
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= (int64_t)C * H * W) return;
+    const int xw = (int)(i % W), y = (int)((i / W) % H), c = (int)(i / ((int64_t)W * H));
+    const float b = ld(bias, c);
+    float s = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = y + ky - 1;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = xw + kx - 1;
+            if (ix < 0 || ix >= W) continue;
+            // activation rounded to the storage type like the reference's smem tile inputs
+            const float av = (float)(T)dcvc_wsiluf(ld(x, ((int64_t)c * H + iy) * W + ix) + b);
+            s = DCVC_FMAF(av, ld(w, c * 9 + ky * 3 + kx), s);
+        }
+    }
+    st(out, i, s);
+}
+
+template <typename F>
+int typed(int dtype, F&& launch)
+{
+    if (dtype == DCVC_F16)
+        launch(half_t{});
+    else if (dtype == DCVC_F32)
+        launch(float{});
+    else {
+        dcvc::set_error("bad dtype %d", dtype);
+        return dcvc::E_ARG;
+    }
+    DCVC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcvc_unshuffle8(int dtype, const void* x, int C, int H, int W, void* out, int64_t ldo, void* stream)
+{
+    DCVC_REQUIRE(x && out && H % 8 == 0 && W % 8 == 0 && ldo >= C * 64, "dcvc_unshuffle8: bad arguments");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        unshuffle8_kernel<T><<<nblocks((int64_t)C * H * W), EB, 0, (hipStream_t)stream>>>((const T*)x, C, H, W, (T*)out, ldo);
+    });
+}
+
+int dcvc_shuffle8_clamp(int dtype, const void* x, int64_t ld_, const float* bias, int C, int H, int W, int do_clamp,
+                        void* out, void* stream)
+{
+    DCVC_REQUIRE(x && out && ld_ >= C * 64, "dcvc_shuffle8_clamp: bad arguments");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        shuffle8_kernel<T><<<nblocks((int64_t)C * H * W * 64), EB, 0, (hipStream_t)stream>>>((const T*)x, ld_, bias, C, H, W, do_clamp, (T*)out);
+    });
+}
+
+int dcvc_replicate_pad_hwc(int dtype, const void* x, int64_t ldx, int H, int W, int C, int pad_b, int pad_r, void* out,
+                           int64_t ldo, void* stream)
+{
+    DCVC_REQUIRE(x && out && pad_b >= 0 && pad_r >= 0 && H > 0 && W > 0, "dcvc_replicate_pad_hwc: bad arguments");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        replicate_pad_hwc_kernel<T><<<nblocks((int64_t)(H + pad_b) * (W + pad_r) * C), EB, 0, (hipStream_t)stream>>>((const T*)x, ldx, H, W, C,
+                     H + pad_b, W + pad_r, (T*)out, ldo);
+    });
+}
+
+int dcvc_scale_channels(int dtype, const void* x, int64_t ldx, const float* q, int64_t P, int C, void* out, int64_t ldo,
+                        void* stream)
+{
+    DCVC_REQUIRE(x && out && q, "dcvc_scale_channels: null pointer");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        scale_channels_kernel<T><<<nblocks(P * C), EB, 0, (hipStream_t)stream>>>((const T*)x, ldx, q, P, C, (T*)out, ldo);
+    });
+}
+
+int dcvc_copy_channels(int dtype, const void* x, int64_t ldx, int64_t P, int C, void* out, int64_t ldo, void* stream)
+{
+    DCVC_REQUIRE(x && out, "dcvc_copy_channels: null pointer");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        copy_channels_kernel<T><<<nblocks(P * C), EB, 0, (hipStream_t)stream>>>((const T*)x, ldx, P, C, (T*)out, ldo);
+    });
+}
+
+int dcvc_crop_hwc(int dtype, const void* x, int64_t ldx, int W, int H2, int W2, int C, void* out, int64_t ldo, void* stream)
+{
+    DCVC_REQUIRE(x && out && W2 <= W, "dcvc_crop_hwc: bad arguments");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        crop_hwc_kernel<T><<<nblocks((int64_t)H2 * W2 * C), EB, 0, (hipStream_t)stream>>>((const T*)x, ldx, W, H2, W2, C, (T*)out, ldo);
+    });
+}
+
+int dcvc_nchw_to_hwc(int dtype, const void* x, int C, int64_t HW, void* out, int64_t ldo, void* stream)
+{
+    DCVC_REQUIRE(x && out && ldo >= C, "dcvc_nchw_to_hwc: bad arguments");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        nchw_to_hwc_kernel<T><<<nblocks(HW * C), EB, 0, (hipStream_t)stream>>>((const T*)x, C, HW, (T*)out, ldo);
+    });
+}
+
+int dcvc_hwc_to_nchw(int dtype, const void* x, int64_t ldx, int C, int64_t HW, void* out, void* stream)
+{
+    DCVC_REQUIRE(x && out && ldx >= C, "dcvc_hwc_to_nchw: bad arguments");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        hwc_to_nchw_kernel<T><<<nblocks(HW * C), EB, 0, (hipStream_t)stream>>>((const T*)x, ldx, C, HW, (T*)out);
+    });
+}
+
+int dcvc_round_z(int dtype, void* z, int64_t ldz, int H, int W, int C, int8_t* z_chw, void* stream)
+{
+    DCVC_REQUIRE(z && z_chw, "dcvc_round_z: null pointer");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        round_z_kernel<T><<<nblocks((int64_t)H * W * C), EB, 0, (hipStream_t)stream>>>((T*)z, ldz, (int64_t)H * W, C, z_chw);
+    });
+}
+
+int dcvc_z_from_int8(int dtype, const int8_t* z_chw, int H, int W, int C, void* out, int64_t ldo, void* stream)
+{
+    DCVC_REQUIRE(z_chw && out, "dcvc_z_from_int8: null pointer");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        z_from_int8_kernel<T><<<nblocks((int64_t)H * W * C), EB, 0, (hipStream_t)stream>>>(z_chw, (int64_t)H * W, C, (T*)out, ldo);
+    });
+}
+
+int dcvc_prior_enc_step(int dtype, int n_groups, int step, int q_mode, const void* y, int64_t ldy, const void* qsrc,
+                        int64_t ldq, const void* scales, int64_t lds_, const void* means, int64_t ldm, int H, int W, int C,
+                        float thres, const void* yhat_in, int64_t ldhi, void* yhat_out, int64_t ldho, int16_t* packed_chw,
+                        void* stream)
+{
+    DCVC_REQUIRE(y && qsrc && scales && means && yhat_out && packed_chw, "dcvc_prior_enc_step: null pointer");
+    DCVC_REQUIRE((n_groups == 2 || n_groups == 4) && step >= 0 && step < n_groups && C % n_groups == 0,
+                 "dcvc_prior_enc_step: bad groups/step %d/%d", n_groups, step);
+    DCVC_REQUIRE(step == 0 || yhat_in, "dcvc_prior_enc_step: yhat_in required after step 0");
+    PriorEncArgs a{n_groups, step, q_mode, y, ldy, qsrc, ldq, scales, lds_, means, ldm, H, W, C, thres,
+                   yhat_in, ldhi, yhat_out, ldho, packed_chw};
+    const int64_t HW = (int64_t)H * W;
+    const int grid = (int)((HW + PT - 1) / PT);
+    const size_t lds = (size_t)(C / n_groups) * PT * sizeof(int16_t);
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        prior_enc_kernel<T><<<grid, EB, lds, (hipStream_t)stream>>>(a);
+    });
+}
+
+int dcvc_prior_dec_index(int dtype, int n_groups, int step, const void* scales, int64_t lds_, int H, int W, int C,
+                         float thres, uint8_t* idx_chw, void* stream)
+{
+    DCVC_REQUIRE(scales && idx_chw, "dcvc_prior_dec_index: null pointer");
+    DCVC_REQUIRE((n_groups == 2 || n_groups == 4) && step >= 0 && step < n_groups && C % n_groups == 0,
+                 "dcvc_prior_dec_index: bad groups/step");
+    const int grid = (int)(((int64_t)H * W + PT - 1) / PT);
+    const size_t lds = (size_t)(C / n_groups) * PT;
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        prior_dec_index_kernel<T><<<grid, EB, lds, (hipStream_t)stream>>>(n_groups,
+                                    step, (const T*)scales, lds_, H, W, C, thres, idx_chw);
+    });
+}
+
+int dcvc_prior_dec_restore(int dtype, int n_groups, int step, const int8_t* sym_chw, const void* means, int64_t ldm, int H,
+                           int W, int C, const void* yhat_in, int64_t ldhi, void* yhat_out, int64_t ldho, void* stream)
+{
+    DCVC_REQUIRE(sym_chw && means && yhat_out, "dcvc_prior_dec_restore: null pointer");
+    DCVC_REQUIRE((n_groups == 2 || n_groups == 4) && step >= 0 && step < n_groups && C % n_groups == 0,
+                 "dcvc_prior_dec_restore: bad groups/step");
+    DCVC_REQUIRE(step == 0 || yhat_in, "dcvc_prior_dec_restore: yhat_in required after step 0");
+    const int grid = (int)(((int64_t)H * W + PT - 1) / PT);
+    const size_t lds = (size_t)(C / n_groups) * PT;
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        prior_dec_restore_kernel<T><<<grid, EB, lds, (hipStream_t)stream>>>(n_groups,
+                                    step, sym_chw, (const T*)means, ldm, H, W, C, (const T*)yhat_in, ldhi, (T*)yhat_out,
+                                    ldho);
+    });
+}
+
+int dcvc_prior_finish(int dtype, int q_mode, void* yhat, int64_t ldh, const void* qsrc, int64_t ldq, int H, int W, int C,
+                      void* stream)
+{
+    DCVC_REQUIRE(yhat && qsrc, "dcvc_prior_finish: null pointer");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        prior_finish_kernel<T><<<nblocks((int64_t)H * W * C), EB, 0, (hipStream_t)stream>>>(q_mode, (T*)yhat, ldh, (const T*)qsrc, ldq,
+                     (int64_t)H * W, C);
+    });
+}
+
+// ---------------------------------------------------------------- operator-module seam
+int dcvc_op_process_with_mask(int dtype, const void* y, const void* scales, const void* means, const void* mask,
+                              float thres, void* y_res, void* y_q, void* y_hat, void* s_hat, int64_t n, void* stream)
+{
+    DCVC_REQUIRE(y && scales && means && mask && y_res && y_q && y_hat && s_hat, "dcvc_op_process_with_mask: null pointer");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        op_process_with_mask_kernel<T><<<nblocks(n), EB, 0, (hipStream_t)stream>>>((const T*)y, (const T*)scales, (const T*)means,
+                     (const T*)mask, thres, (T*)y_res, (T*)y_q, (T*)y_hat, (T*)s_hat, n);
+    });
+}
+
+int dcvc_op_combine_for_reading_2x(int dtype, void* out, const void* x, const void* mask, int64_t half_n, void* stream)
+{
+    DCVC_REQUIRE(out && x && mask, "dcvc_op_combine_for_reading_2x: null pointer");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        op_combine_2x_kernel<T><<<nblocks(half_n), EB, 0, (hipStream_t)stream>>>((T*)out, (const T*)x, (const T*)mask, half_n);
+    });
+}
+
+int dcvc_op_restore_y_2x(int dtype, void* out, const void* y, const void* means, const void* mask, int64_t half_n,
+                         void* stream)
+{
+    DCVC_REQUIRE(out && y && means && mask, "dcvc_op_restore_y_2x: null pointer");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        op_restore_kernel<T><<<nblocks(half_n), EB, 0, (hipStream_t)stream>>>((T*)out, (const T*)y, (const T*)means, (const T*)mask, half_n, 2);
+    });
+}
+
+int dcvc_op_restore_y_4x(int dtype, void* out, const void* y, const void* means, const void* mask, int64_t quarter_n,
+                         void* stream)
+{
+    DCVC_REQUIRE(out && y && means && mask, "dcvc_op_restore_y_4x: null pointer");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        op_restore_kernel<T><<<nblocks(quarter_n), EB, 0, (hipStream_t)stream>>>((T*)out, (const T*)y, (const T*)means, (const T*)mask, quarter_n, 4);
+    });
+}
+
+int dcvc_op_build_index_dec(int dtype, uint8_t* out, uint8_t* cond_out, const void* scales, float scale_min,
+                            float scale_max, float log_scale_min, float log_step_recip, float skip_thres, int64_t n,
+                            void* stream)
+{
+    DCVC_REQUIRE(out && scales, "dcvc_op_build_index_dec: null pointer");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        op_build_index_kernel<T><<<nblocks(n), EB, 0, (hipStream_t)stream>>>((int16_t*)nullptr, out, cond_out, (const T*)nullptr,
+                     (const T*)scales, scale_min, scale_max, log_scale_min, log_step_recip, skip_thres, n);
+    });
+}
+
+int dcvc_op_build_index_enc(int dtype, int16_t* out, uint8_t* cond_out, const void* symbols, const void* scales,
+                            float scale_min, float scale_max, float log_scale_min, float log_step_recip,
+                            float skip_thres, int64_t n, void* stream)
+{
+    DCVC_REQUIRE(out && symbols && scales, "dcvc_op_build_index_enc: null pointer");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        op_build_index_kernel<T><<<nblocks(n), EB, 0, (hipStream_t)stream>>>(out, (uint8_t*)nullptr, cond_out, (const T*)symbols,
+                     (const T*)scales, scale_min, scale_max, log_scale_min, log_step_recip, skip_thres, n);
+    });
+}
+
+int dcvc_op_round_and_to_int8(int dtype, void* z, int8_t* z_int8, int64_t n, void* stream)
+{
+    DCVC_REQUIRE(z && z_int8, "dcvc_op_round_and_to_int8: null pointer");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        op_round_int8_kernel<T><<<nblocks(n), EB, 0, (hipStream_t)stream>>>((T*)z, z_int8, n);
+    });
+}
+
+int dcvc_op_clamp_reciprocal_with_quant(int dtype, const void* q_dec, void* y, float min_val, void* q_out, int64_t n,
+                                        void* stream)
+{
+    DCVC_REQUIRE(q_dec && y && q_out, "dcvc_op_clamp_reciprocal_with_quant: null pointer");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        op_clamp_recip_kernel<T><<<nblocks(n), EB, 0, (hipStream_t)stream>>>((const T*)q_dec, (T*)y, min_val, (T*)q_out, n);
+    });
+}
+
+int dcvc_op_add_and_multiply(int dtype, void* x0, const void* x1, const void* q, int64_t n, void* stream)
+{
+    DCVC_REQUIRE(x0 && x1 && q, "dcvc_op_add_and_multiply: null pointer");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        op_add_mul_kernel<T><<<nblocks(n), EB, 0, (hipStream_t)stream>>>((T*)x0, (const T*)x1, (const T*)q, n);
+    });
+}
+
+int dcvc_op_bias_quant(int dtype, void* x, const void* bias, const void* quant, int C, int64_t HW, void* stream)
+{
+    DCVC_REQUIRE(x && bias && quant, "dcvc_op_bias_quant: null pointer");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        op_bias_quant_kernel<T><<<nblocks(HW * C), EB, 0, (hipStream_t)stream>>>((T*)x, (const T*)bias, (const T*)quant, C, HW);
+    });
+}
+
+int dcvc_op_bias_pixel_shuffle_8(int dtype, void* out, const void* x, const void* bias, int C, int H, int W, int do_clamp,
+                                 void* stream)
+{
+    DCVC_REQUIRE(out && x && bias && C % 64 == 0, "dcvc_op_bias_pixel_shuffle_8: bad arguments");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        op_ps8_kernel<T><<<nblocks((int64_t)C * H * W), EB, 0, (hipStream_t)stream>>>((T*)out, (const T*)x, (const T*)bias, C, H, W, do_clamp);
+    });
+}
+
+int dcvc_op_replicate_pad(int dtype, const void* x, int C, int H, int W, int pad_b, int pad_r, void* out, void* stream)
+{
+    DCVC_REQUIRE(x && out && pad_b >= 0 && pad_r >= 0, "dcvc_op_replicate_pad: bad arguments");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        op_replicate_pad_kernel<T><<<nblocks((int64_t)C * (H + pad_b) * (W + pad_r)), EB, 0, (hipStream_t)stream>>>((const T*)x, C, H, W,
+                     H + pad_b, W + pad_r, (T*)out);
+    });
+}
+
+int dcvc_op_bias_wsilu_depthwise_conv2d(int dtype, const void* x, const void* weight, const void* bias, int C, int H,
+                                        int W, void* out, void* stream)
+{
+    DCVC_REQUIRE(x && weight && bias && out, "dcvc_op_bias_wsilu_depthwise_conv2d: null pointer");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        op_bias_wsilu_dw_kernel<T><<<nblocks((int64_t)C * H * W), EB, 0, (hipStream_t)stream>>>((const T*)x, (const T*)weight, (const T*)bias, C,
+                     H, W, (T*)out);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,760 @@
+// dcvc_nn.hip - the convolutional hot path of DCVC-RT on gfx950: fused DepthConvBlock
+// (2 kernels instead of the reference's 8 launches, impl.cpp:53-121) and implicit-GEMM dense
+// convolutions (1x1, 3x3 s1/s2, 2x2 s2) with fused bias / quant / PixelShuffle(2) / WSiLU epilogues.
+// Decomposition and operand layouts: gemm_core.hpp.  C ABI: include/dcvc_amd.h.
+#include <functional>
+#include <memory>
+#include <vector>
+
+#include "common.hpp"
+#include "gemm_core.hpp"
+
+namespace {
+
+using dcvc::round_up;
+
+// ------------------------------------------------------------------------------------------
+// tile geometry: M = 16*MT pixels arranged TH x 8
+template <int MT>
+struct Tile {
+    static constexpr int M = 16 * MT;
+    static constexpr int TW = 8;
+    static constexpr int TH = M / TW;
+};
+
+struct SrcPair {   // channel-concat of up to two HWC sources
+    const void* x0;
+    long ld0;
+    int c0;
+    const void* x1;
+    long ld1;
+    int c1;
+};
+
+// Loads channels [c, c+kVec) of the concat input at pixel index `pix` (or zeros if !valid).
+template <typename T>
+__device__ __forceinline__ Vec16 load_src(const SrcPair& s, long pix, int c, bool valid)
+{
+    Vec16 v{{0u, 0u, 0u, 0u}};
+    if (valid) {
+        if (c < s.c0)
+            v = *reinterpret_cast<const Vec16*>(reinterpret_cast<const T*>(s.x0) + pix * s.ld0 + c);
+        else
+            v = *reinterpret_cast<const Vec16*>(reinterpret_cast<const T*>(s.x1) + pix * s.ld1 + (c - s.c0));
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// DepthConvBlock, first kernel:  x -> [x' = adaptor(x)] -> a = wsilu(conv1(x') + b1)
+struct HeadParams {
+    SrcPair src;
+    int H, W, C;   // C: physical channel count of the block
+    const void* wa;
+    const float* ba;
+    void* ident;
+    long ldi;
+    const void* w1;
+    const float* b1;
+    void* a_out;
+    long lda;
+};
+
+template <typename T, int MT, int NTW, bool ADAPT>
+__global__ __launch_bounds__(NTHREADS) void dcb_head_kernel(HeadParams p)
+{
+    using TR = Traits<T>;
+    using frag_t = typename TR::frag_t;
+    constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Kin = p.src.c0 + p.src.c1;
+    const int ldx = Kin + TR::kPad;
+    const int ldy = p.C + TR::kPad;
+    T* bufX = reinterpret_cast<T*>(smem);
+    T* bufY = bufX + M * ldx;
+
+    const int tiles_x = (p.W + TW - 1) / TW;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+
+    {   // stage the input tile
+        const int G = Kin / TR::kVec;
+        for (int it = tid; it < M * G; it += NTHREADS) {
+            const int m = it / G, c = (it - m * G) * TR::kVec;
+            const int y = ty0 + m / TW, x = tx0 + m % TW;
+            const bool valid = (y < p.H) && (x < p.W);
+            lds_store_vec<T>(bufX, ldx, m, c, load_src<T>(p.src, (long)y * p.W + x, c, valid));
+        }
+    }
+    __syncthreads();
+
+    int tiles[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) tiles[i] = wave + NWAVE * i;
+    const int cq = lane & 15, rq = (lane >> 4) * 4;
+    floatx4 acc[MT][NTW];
+
+    if (ADAPT) {
+        zero_acc(acc);
+        gemm_acc<T, MT, NTW>(acc, bufX, ldx, Kin / KG, reinterpret_cast<const frag_t*>(p.wa), Kin / KG, 0, tiles, lane);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const int col = tiles[i] * 16 + cq;
+            const float bias = p.ba[col];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m * 16 + rq + r;
+                    const int y = ty0 + row / TW, x = tx0 + row % TW;
+                    const T v = TR::from_f(acc[m][i][r] + bias);
+                    bufY[row * ldy + TR::perm(col)] = v;
+                    if (y < p.H && x < p.W)
+                        reinterpret_cast<T*>(p.ident)[((long)y * p.W + x) * p.ldi + col] = v;
+                }
+        }
+        __syncthreads();
+    }
+
+    zero_acc(acc);
+    if (ADAPT)
+        gemm_acc<T, MT, NTW>(acc, bufY, ldy, p.C / KG, reinterpret_cast<const frag_t*>(p.w1), p.C / KG, 0, tiles, lane);
+    else
+        gemm_acc<T, MT, NTW>(acc, bufX, ldx, Kin / KG, reinterpret_cast<const frag_t*>(p.w1), Kin / KG, 0, tiles, lane);
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int col = tiles[i] * 16 + cq;
+        const float bias = p.b1[col];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m * 16 + rq + r;
+                const int y = ty0 + row / TW, x = tx0 + row % TW;
+                if (y < p.H && x < p.W)
+                    reinterpret_cast<T*>(p.a_out)[((long)y * p.W + x) * p.lda + col] =
+                        TR::from_f(dcvc_wsiluf(acc[m][i][r] + bias));
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// DepthConvBlock, second kernel:
+//   d = dw3x3(a) + bd;  o = (W2 d + b2) + x';  v = wsilu(u_lo) + wsilu(u_hi), u = W3 o + b3;
+//   out = ((W4 v + b4) + o) [+ x'] [* q]
+struct TailParams {
+    const void* a;
+    long lda;
+    const void* ident;
+    long ldi;
+    int H, W, C, c_log;
+    const void* wd;      // [9][C] T
+    const float* bd;
+    const void* w2;
+    const float* b2;
+    const void* w3;
+    const float* b3;     // [4C] : lo half | hi half
+    const void* w4;
+    const float* b4;
+    int shortcut;
+    const float* q;      // device, c_log entries, or NULL
+    void* out;
+    long ldo;
+};
+
+template <typename T, int MT, int NTW>
+__global__ __launch_bounds__(NTHREADS) void dcb_tail_kernel(TailParams p)
+{
+    using TR = Traits<T>;
+    using frag_t = typename TR::frag_t;
+    constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH;
+    constexpr int NTV = 2;                        // v tiles per wave per chunk
+    constexpr int VC = NWAVE * NTV * 16;          // 128 v columns per chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = p.C;
+    const int ldx = C + TR::kPad;
+    constexpr int ldv = VC + TR::kPad;
+    T* bufX = reinterpret_cast<T*>(smem);
+    T* bufV = bufX + M * ldx;
+
+    const int tiles_x = (p.W + TW - 1) / TW;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const T* a = reinterpret_cast<const T*>(p.a);
+    const T* ident = reinterpret_cast<const T*>(p.ident);
+
+    {   // depthwise 3x3 (zero padding) of the activation, taps in (ky,kx) order, + bias
+        constexpr int V = TR::kVec;
+        const int G = C / V;
+        const T* wd = reinterpret_cast<const T*>(p.wd);
+        for (int it = tid; it < M * G; it += NTHREADS) {
+            const int m = it / G, c = (it - m * G) * V;
+            const int y = ty0 + m / TW, x = tx0 + m % TW;
+            float s[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) s[j] = 0.f;
+            if (y < p.H && x < p.W) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int iy = y + ky - 1;
+                    if (iy < 0 || iy >= p.H) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int ix = x + kx - 1;
+                        if (ix < 0 || ix >= p.W) continue;
+                        float av[V], wv[V];
+                        unpack16<T>(*reinterpret_cast<const Vec16*>(a + ((long)iy * p.W + ix) * p.lda + c), av);
+                        unpack16<T>(*reinterpret_cast<const Vec16*>(wd + (ky * 3 + kx) * C + c), wv);
+#pragma unroll
+                        for (int j = 0; j < V; ++j) s[j] = DCVC_FMAF(av[j], wv[j], s[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < V; ++j) s[j] = s[j] + p.bd[c + j];
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) bufX[m * ldx + TR::perm(c + j)] = TR::from_f(s[j]);
+        }
+    }
+    __syncthreads();
+
+    int tiles[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) tiles[i] = wave + NWAVE * i;
+    const int cq = lane & 15, rq = (lane >> 4) * 4;
+
+    floatx4 acc[MT][NTW];
+    zero_acc(acc);
+    gemm_acc<T, MT, NTW>(acc, bufX, ldx, C / KG, reinterpret_cast<const frag_t*>(p.w2), C / KG, 0, tiles, lane);
+    __syncthreads();   // every wave has finished reading d
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int col = tiles[i] * 16 + cq;
+        const float bias = p.b2[col];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m * 16 + rq + r;
+                const int y = ty0 + row / TW, x = tx0 + row % TW;
+                float idv = 0.f;
+                if (y < p.H && x < p.W) idv = TR::to_f(ident[((long)y * p.W + x) * p.ldi + col]);
+                bufX[row * ldx + TR::perm(col)] = TR::from_f((acc[m][i][r] + bias) + idv);
+            }
+    }
+    __syncthreads();
+
+    // FFN: C -> 4C -> chunk-add -> 2C -> C, the 4C-wide intermediate never leaves the CU
+    zero_acc(acc);
+    const int vtiles = 2 * C / 16;
+    const int chunks = vtiles / (NWAVE * NTV);
+    for (int ch = 0; ch < chunks; ++ch) {
+        floatx4 u[MT][2 * NTV];
+        zero_acc(u);
+        int ut[2 * NTV];
+#pragma unroll
+        for (int j = 0; j < NTV; ++j) {
+            ut[j] = ch * NWAVE * NTV + wave * NTV + j;
+            ut[j + NTV] = ut[j] + vtiles;
+        }
+        gemm_acc<T, MT, 2 * NTV>(u, bufX, ldx, C / KG, reinterpret_cast<const frag_t*>(p.w3), C / KG, 0, ut, lane);
+#pragma unroll
+        for (int j = 0; j < NTV; ++j) {
+            const int vcol = ut[j] * 16 + cq;
+            const float blo = p.b3[vcol], bhi = p.b3[vcol + 2 * C];
+            const int lcol = (wave * NTV + j) * 16 + cq;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m * 16 + rq + r;
+                    const float v = dcvc_wsiluf(u[m][j][r] + blo) + dcvc_wsiluf(u[m][j + NTV][r] + bhi);
+                    bufV[row * ldv + TR::perm(lcol)] = TR::from_f(v);
+                }
+        }
+        __syncthreads();
+        gemm_acc<T, MT, NTW>(acc, bufV, ldv, VC / KG, reinterpret_cast<const frag_t*>(p.w4), 2 * C / KG,
+                             ch * (VC / KG), tiles, lane);
+        __syncthreads();
+    }
+
+    T* out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int col = tiles[i] * 16 + cq;
+        const float bias = p.b4[col];
+        const float qv = (p.q != nullptr && col < p.c_log) ? p.q[col] : 1.0f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m * 16 + rq + r;
+                const int y = ty0 + row / TW, x = tx0 + row % TW;
+                if (y < p.H && x < p.W) {
+                    const long pix = (long)y * p.W + x;
+                    float v = (acc[m][i][r] + bias) + TR::to_f(bufX[row * ldx + TR::perm(col)]);
+                    if (p.shortcut) v = v + TR::to_f(ident[pix * p.ldi + col]);
+                    if (p.q != nullptr) v = v * qv;
+                    out[pix * p.ldo + col] = TR::from_f(v);
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Dense convolution as implicit GEMM over (tap, cin)
+struct ConvParams {
+    SrcPair src;
+    int H, W, Ho, Wo;
+    int KH, KW, stride, pad;
+    int N, n_log, cs_p;
+    const void* w;
+    const float* b;
+    const float* q;
+    int epi;
+    void* out;
+    long ldo;
+};
+
+template <typename T, int MT, int NTW>
+__global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvParams p)
+{
+    using TR = Traits<T>;
+    using frag_t = typename TR::frag_t;
+    constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Kin = p.src.c0 + p.src.c1;
+    const int ldx = Kin + TR::kPad;
+    T* bufX = reinterpret_cast<T*>(smem);
+    const int tiles_x = (p.Wo + TW - 1) / TW;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const int taps = p.KH * p.KW, kgin = Kin / KG, ntiles = p.N / 16;
+    const int passes = (ntiles + NWAVE * NTW - 1) / (NWAVE * NTW);
+    const int cq = lane & 15, rq = (lane >> 4) * 4;
+    const int G = Kin / TR::kVec;
+    T* out = reinterpret_cast<T*>(p.out);
+
+    auto stage = [&](int tap) {
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        for (int it = tid; it < M * G; it += NTHREADS) {
+            const int m = it / G, c = (it - m * G) * TR::kVec;
+            const int oy = ty0 + m / TW, ox = tx0 + m % TW;
+            const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+            const bool valid = (oy < p.Ho) && (ox < p.Wo) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            lds_store_vec<T>(bufX, ldx, m, c, load_src<T>(p.src, (long)iy * p.W + ix, c, valid));
+        }
+    };
+
+    if (taps == 1) {
+        stage(0);
+        __syncthreads();
+    }
+    for (int pass = 0; pass < passes; ++pass) {
+        int tiles[NTW];
+        bool tvalid[NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const int t = pass * NWAVE * NTW + wave + NWAVE * i;
+            tvalid[i] = t < ntiles;
+            tiles[i] = tvalid[i] ? t : ntiles - 1;
+        }
+        floatx4 acc[MT][NTW];
+        zero_acc(acc);
+        if (taps == 1) {
+            gemm_acc<T, MT, NTW>(acc, bufX, ldx, kgin, reinterpret_cast<const frag_t*>(p.w), kgin, 0, tiles, lane);
+        } else {
+            for (int tap = 0; tap < taps; ++tap) {
+                __syncthreads();
+                stage(tap);
+                __syncthreads();
+                gemm_acc<T, MT, NTW>(acc, bufX, ldx, kgin, reinterpret_cast<const frag_t*>(p.w), taps * kgin,
+                                     tap * kgin, tiles, lane);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            if (!tvalid[i]) continue;
+            const int col = tiles[i] * 16 + cq;
+            const float bias = p.b[col];
+            const float qv = (p.epi == DCVC_EPI_BIAS_QUANT && col < p.n_log) ? p.q[col] : 1.0f;
+            int sdy = 0, sdx = 0, scol = col;
+            if (p.epi == DCVC_EPI_SHUFFLE2) {
+                const int s = col / p.cs_p;
+                scol = col - s * p.cs_p;
+                sdy = s >> 1;
+                sdx = s & 1;
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m * 16 + rq + r;
+                    const int oy = ty0 + row / TW, ox = tx0 + row % TW;
+                    if (oy >= p.Ho || ox >= p.Wo) continue;
+                    float v = acc[m][i][r] + bias;
+                    if (p.epi == DCVC_EPI_BIAS_QUANT) v = v * qv;
+                    if (p.epi == DCVC_EPI_WSILU) v = dcvc_wsiluf(v);
+                    if (p.epi == DCVC_EPI_SHUFFLE2)
+                        out[((long)(2 * oy + sdy) * (2 * p.Wo) + (2 * ox + sdx)) * p.ldo + scol] = TR::from_f(v);
+                    else
+                        out[((long)oy * p.Wo + ox) * p.ldo + col] = TR::from_f(v);
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: weight packing and handles
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    int upload(const void* src, size_t bytes)
+    {
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {
+            p = nullptr;
+            dcvc::set_error("hipMalloc(%zu) failed", bytes);
+            return dcvc::E_MEM;
+        }
+        if (bytes && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            dcvc::set_error("hipMemcpy H2D failed");
+            return dcvc::E_HIP;
+        }
+        return 0;
+    }
+};
+
+// get(n, k) -> logical weight (0 outside the logical range)
+template <typename T>
+int pack_upload(DevBuf& dst, int Np, int Kp, const std::function<float(int, int)>& get)
+{
+    const int kgs = Kp / KG, nt = Np / 16;
+    std::vector<T> buf((size_t)nt * kgs * 64 * 8);
+    for (int t = 0; t < nt; ++t)
+        for (int g = 0; g < kgs; ++g)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 15, q = lane >> 4;
+                for (int j = 0; j < 8; ++j) {
+                    const int k = g * KG + (sizeof(T) == 2 ? 8 * q + j : 4 * j + q);
+                    buf[(((size_t)t * kgs + g) * 64 + lane) * 8 + j] = (T)get(t * 16 + r, k);
+                }
+            }
+    return dst.upload(buf.data(), buf.size() * sizeof(T));
+}
+
+int pack_any(int dtype, DevBuf& dst, int Np, int Kp, const std::function<float(int, int)>& get)
+{
+    return dtype == DCVC_F16 ? pack_upload<half_t>(dst, Np, Kp, get) : pack_upload<float>(dst, Np, Kp, get);
+}
+
+int upload_f32(DevBuf& dst, int n, const std::function<float(int)>& get)
+{
+    std::vector<float> v(n);
+    for (int i = 0; i < n; ++i) v[i] = get(i);
+    return dst.upload(v.data(), v.size() * sizeof(float));
+}
+
+template <typename T>
+int upload_T(DevBuf& dst, int n, const std::function<float(int)>& get)
+{
+    std::vector<T> v(n);
+    for (int i = 0; i < n; ++i) v[i] = (T)get(i);
+    return dst.upload(v.data(), v.size() * sizeof(T));
+}
+
+}  // namespace
+
+struct dcvc_dcb {
+    int dtype, cin, c, cin_p, c_p, shortcut, adapt;
+    DevBuf wa, ba, w1, b1, wd, bd, w2, b2, w3, b3, w4, b4;
+};
+
+struct dcvc_conv {
+    int dtype, cin, cout, cin_p, n_p, cs_p, kh, kw, stride, pad, epi;
+    DevBuf w, b;
+};
+
+namespace {
+
+template <typename T, int MT>
+size_t head_lds(int kin, int c, bool adapt)
+{
+    return (size_t)Tile<MT>::M * ((kin + Traits<T>::kPad) + (adapt ? c + Traits<T>::kPad : 0)) * sizeof(T);
+}
+template <typename T, int MT>
+size_t tail_lds(int c)
+{
+    return (size_t)Tile<MT>::M * ((c + Traits<T>::kPad) + (128 + Traits<T>::kPad)) * sizeof(T);
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes)
+{
+    if (bytes > 160 * 1024) {
+        dcvc::set_error("kernel needs %zu bytes of LDS (> 160 KiB)", bytes);
+        return dcvc::E_ARG;
+    }
+    if (bytes > 64 * 1024)
+        DCVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+template <typename T, int MT, int NTW>
+int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float* quant, void* out, int64_t ldo,
+               void* scratch, hipStream_t st)
+{
+    const int C = h->c_p;
+    const int grid = ((H + Tile<MT>::TH - 1) / Tile<MT>::TH) * ((W + Tile<MT>::TW - 1) / Tile<MT>::TW);
+    const size_t P = (size_t)H * W;
+    T* a_buf = reinterpret_cast<T*>(scratch);
+    T* id_buf = a_buf + P * C;
+    HeadParams hp{};
+    hp.src = src;
+    hp.H = H;
+    hp.W = W;
+    hp.C = C;
+    hp.wa = h->wa.p;
+    hp.ba = (const float*)h->ba.p;
+    hp.ident = id_buf;
+    hp.ldi = C;
+    hp.w1 = h->w1.p;
+    hp.b1 = (const float*)h->b1.p;
+    hp.a_out = a_buf;
+    hp.lda = C;
+    const int kin = src.c0 + src.c1;
+    if (h->adapt) {
+        const size_t lds = head_lds<T, MT>(kin, C, true);
+        int rc = set_lds(dcb_head_kernel<T, MT, NTW, true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((dcb_head_kernel<T, MT, NTW, true>), dim3(grid), dim3(NTHREADS), lds, st, hp);
+    } else {
+        const size_t lds = head_lds<T, MT>(kin, C, false);
+        int rc = set_lds(dcb_head_kernel<T, MT, NTW, false>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((dcb_head_kernel<T, MT, NTW, false>), dim3(grid), dim3(NTHREADS), lds, st, hp);
+    }
+    DCVC_LAUNCH_CHECK();
+    TailParams tp{};
+    tp.a = a_buf;
+    tp.lda = C;
+    tp.ident = h->adapt ? (const void*)id_buf : src.x0;
+    tp.ldi = h->adapt ? C : src.ld0;
+    tp.H = H;
+    tp.W = W;
+    tp.C = C;
+    tp.c_log = h->c;
+    tp.wd = h->wd.p;
+    tp.bd = (const float*)h->bd.p;
+    tp.w2 = h->w2.p;
+    tp.b2 = (const float*)h->b2.p;
+    tp.w3 = h->w3.p;
+    tp.b3 = (const float*)h->b3.p;
+    tp.w4 = h->w4.p;
+    tp.b4 = (const float*)h->b4.p;
+    tp.shortcut = h->shortcut;
+    tp.q = quant;
+    tp.out = out;
+    tp.ldo = ldo;
+    const size_t lds = tail_lds<T, MT>(C);
+    int rc = set_lds(dcb_tail_kernel<T, MT, NTW>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((dcb_tail_kernel<T, MT, NTW>), dim3(grid), dim3(NTHREADS), lds, st, tp);
+    DCVC_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, int MT>
+int dispatch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float* quant, void* out, int64_t ldo,
+                 void* scratch, hipStream_t st)
+{
+    switch (h->c_p / 64) {
+    case 2: return launch_dcb<T, MT, 2>(h, src, H, W, quant, out, ldo, scratch, st);
+    case 3: return launch_dcb<T, MT, 3>(h, src, H, W, quant, out, ldo, scratch, st);
+    case 4: return launch_dcb<T, MT, 4>(h, src, H, W, quant, out, ldo, scratch, st);
+    case 5: return launch_dcb<T, MT, 5>(h, src, H, W, quant, out, ldo, scratch, st);
+    case 6: return launch_dcb<T, MT, 6>(h, src, H, W, quant, out, ldo, scratch, st);
+    case 8: return launch_dcb<T, MT, 8>(h, src, H, W, quant, out, ldo, scratch, st);
+    default: dcvc::set_error("DepthConvBlock width %d not instantiated", h->c_p); return dcvc::E_ARG;
+    }
+}
+
+template <typename T, int MT, int NTW>
+int launch_conv(const dcvc_conv* h, const ConvParams& cp, hipStream_t st)
+{
+    const int grid = ((cp.Ho + Tile<MT>::TH - 1) / Tile<MT>::TH) * ((cp.Wo + Tile<MT>::TW - 1) / Tile<MT>::TW);
+    const size_t lds = (size_t)Tile<MT>::M * (cp.src.c0 + cp.src.c1 + Traits<T>::kPad) * sizeof(T);
+    int rc = set_lds(conv_kernel<T, MT, NTW>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((conv_kernel<T, MT, NTW>), dim3(grid), dim3(NTHREADS), lds, st, cp);
+    DCVC_LAUNCH_CHECK();
+    (void)h;
+    return 0;
+}
+
+template <typename T, int MT>
+int dispatch_conv(const dcvc_conv* h, const ConvParams& cp, hipStream_t st)
+{
+    const int nt = cp.N / 16;
+    if (nt <= 8) return launch_conv<T, MT, 2>(h, cp, st);
+    if (nt <= 12) return launch_conv<T, MT, 3>(h, cp, st);
+    return launch_conv<T, MT, 4>(h, cp, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcvc_dcb_create(int dtype, int cin, int c, int shortcut, const float* adaptor_w, const float* adaptor_b,
+                    const float* w1, const float* b1, const float* wd, const float* bd, const float* w2,
+                    const float* b2, const float* w3, const float* b3, const float* w4, const float* b4,
+                    dcvc_dcb** out)
+{
+    DCVC_REQUIRE(out && w1 && b1 && wd && bd && w2 && b2 && w3 && b3 && w4 && b4, "dcvc_dcb_create: null weight pointer");
+    DCVC_REQUIRE(dtype == DCVC_F16 || dtype == DCVC_F32, "dcvc_dcb_create: bad dtype %d", dtype);
+    DCVC_REQUIRE(c > 0 && cin > 0 && (adaptor_w != nullptr || cin == c), "dcvc_dcb_create: cin %d != c %d needs an adaptor", cin, c);
+    std::unique_ptr<dcvc_dcb> h(new dcvc_dcb());
+    h->dtype = dtype;
+    h->cin = cin;
+    h->c = c;
+    h->shortcut = shortcut ? 1 : 0;
+    h->adapt = adaptor_w != nullptr;
+    const int Cp = h->c_p = round_up(c, 64);
+    const int Kp = h->cin_p = h->adapt ? round_up(cin, 32) : Cp;
+    const int C = c;
+    int rc = 0;
+    if (h->adapt) {
+        rc |= pack_any(dtype, h->wa, Cp, Kp, [&](int n, int k) { return (n < C && k < cin) ? adaptor_w[(size_t)n * cin + k] : 0.f; });
+        rc |= upload_f32(h->ba, Cp, [&](int n) { return n < C ? adaptor_b[n] : 0.f; });
+    }
+    rc |= pack_any(dtype, h->w1, Cp, Cp, [&](int n, int k) { return (n < C && k < C) ? w1[(size_t)n * C + k] : 0.f; });
+    rc |= upload_f32(h->b1, Cp, [&](int n) { return n < C ? b1[n] : 0.f; });
+    auto dwget = [&](int i) { const int t = i / Cp, ch = i % Cp; return ch < C ? wd[(size_t)ch * 9 + t] : 0.f; };
+    rc |= dtype == DCVC_F16 ? upload_T<half_t>(h->wd, 9 * Cp, dwget) : upload_T<float>(h->wd, 9 * Cp, dwget);
+    rc |= upload_f32(h->bd, Cp, [&](int n) { return n < C ? bd[n] : 0.f; });
+    rc |= pack_any(dtype, h->w2, Cp, Cp, [&](int n, int k) { return (n < C && k < C) ? w2[(size_t)n * C + k] : 0.f; });
+    rc |= upload_f32(h->b2, Cp, [&](int n) { return n < C ? b2[n] : 0.f; });
+    // ffn.0: logical rows [0,2C) pair with rows [2C,4C) (WSiLUChunkAdd); physical halves are 2*Cp wide
+    auto u_row = [&](int n) { const int half = n / (2 * Cp), cc = n % (2 * Cp); return cc < 2 * C ? half * 2 * C + cc : -1; };
+    rc |= pack_any(dtype, h->w3, 4 * Cp, Cp, [&](int n, int k) { const int rr = u_row(n); return (rr >= 0 && k < C) ? w3[(size_t)rr * C + k] : 0.f; });
+    rc |= upload_f32(h->b3, 4 * Cp, [&](int n) { const int rr = u_row(n); return rr >= 0 ? b3[rr] : 0.f; });
+    rc |= pack_any(dtype, h->w4, Cp, 2 * Cp, [&](int n, int k) { return (n < C && k < 2 * C) ? w4[(size_t)n * 2 * C + k] : 0.f; });
+    rc |= upload_f32(h->b4, Cp, [&](int n) { return n < C ? b4[n] : 0.f; });
+    if (rc) return rc < 0 ? rc : dcvc::E_MEM;
+    *out = h.release();
+    return 0;
+}
+
+void dcvc_dcb_destroy(dcvc_dcb* h) { delete h; }
+
+size_t dcvc_dcb_scratch_bytes(const dcvc_dcb* h, int H, int W)
+{
+    if (!h) return 0;
+    return (size_t)H * W * h->c_p * dcvc::elem_size(h->dtype) * 2;
+}
+
+int dcvc_dcb_forward(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, const void* x1, int64_t ld1, int c1,
+                     int H, int W, const float* quant, void* out, int64_t ldo, void* scratch, void* stream)
+{
+    DCVC_REQUIRE(h && x0 && out && scratch, "dcvc_dcb_forward: null pointer");
+    DCVC_REQUIRE(H > 0 && W > 0, "dcvc_dcb_forward: empty input %dx%d", H, W);
+    DCVC_REQUIRE(c0 % 32 == 0 && c1 % 32 == 0 && c0 + c1 == h->cin_p,
+                 "dcvc_dcb_forward: input channels %d+%d do not match the block (%d physical)", c0, c1, h->cin_p);
+    DCVC_REQUIRE((x1 != nullptr) == (c1 > 0), "dcvc_dcb_forward: x1/c1 mismatch");
+    DCVC_REQUIRE(h->adapt || c1 == 0, "dcvc_dcb_forward: a block without adaptor takes a single source");
+    DCVC_REQUIRE(ld0 >= c0 && ldo >= h->c_p && (c1 == 0 || ld1 >= c1), "dcvc_dcb_forward: row stride too small");
+    const size_t es = dcvc::elem_size(h->dtype);
+    DCVC_REQUIRE(((uintptr_t)x0 % 16) == 0 && (ld0 * es) % 16 == 0 && (c1 == 0 || (((uintptr_t)x1 % 16) == 0 && (ld1 * es) % 16 == 0)),
+                 "dcvc_dcb_forward: inputs must be 16-byte aligned");
+    SrcPair src{x0, (long)ld0, c0, x1, (long)ld1, c1};
+    hipStream_t st = (hipStream_t)stream;
+    if (h->dtype == DCVC_F16) return dispatch_dcb<half_t, 4>(h, src, H, W, quant, out, ldo, scratch, st);
+    return dispatch_dcb<float, 2>(h, src, H, W, quant, out, ldo, scratch, st);
+}
+
+int dcvc_conv_create(int dtype, int cin, int cout, int kh, int kw, int stride, int pad, int epilogue,
+                     const float* w, const float* b, dcvc_conv** out)
+{
+    DCVC_REQUIRE(out && w && b, "dcvc_conv_create: null pointer");
+    DCVC_REQUIRE(dtype == DCVC_F16 || dtype == DCVC_F32, "dcvc_conv_create: bad dtype %d", dtype);
+    DCVC_REQUIRE(kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3 && stride >= 1 && stride <= 2 && pad >= 0 && pad <= 1,
+                 "dcvc_conv_create: unsupported geometry k=%dx%d s=%d p=%d", kh, kw, stride, pad);
+    DCVC_REQUIRE(epilogue >= DCVC_EPI_BIAS && epilogue <= DCVC_EPI_WSILU, "dcvc_conv_create: bad epilogue %d", epilogue);
+    DCVC_REQUIRE(epilogue != DCVC_EPI_SHUFFLE2 || cout % 4 == 0, "dcvc_conv_create: shuffle needs cout %% 4 == 0");
+    std::unique_ptr<dcvc_conv> h(new dcvc_conv());
+    h->dtype = dtype;
+    h->cin = cin;
+    h->cout = cout;
+    h->kh = kh;
+    h->kw = kw;
+    h->stride = stride;
+    h->pad = pad;
+    h->epi = epilogue;
+    const int Kp = h->cin_p = round_up(cin, 32);
+    const int taps = kh * kw;
+    int Np;
+    std::function<int(int)> to_log;   // physical output channel -> logical (or -1)
+    if (epilogue == DCVC_EPI_SHUFFLE2) {
+        const int cs = cout / 4, csp = h->cs_p = round_up(cs, 32);
+        Np = 4 * csp;
+        to_log = [=](int n) { const int s = n / csp, cc = n % csp; return cc < cs ? cc * 4 + s : -1; };
+    } else {
+        h->cs_p = 0;
+        Np = round_up(cout, 32);
+        to_log = [=](int n) { return n < cout ? n : -1; };
+    }
+    h->n_p = Np;
+    int rc = pack_any(dtype, h->w, Np, taps * Kp, [&](int n, int k) {
+        const int nl = to_log(n), t = k / Kp, ci = k % Kp;
+        return (nl >= 0 && ci < cin) ? w[((size_t)nl * cin + ci) * taps + t] : 0.f;
+    });
+    rc |= upload_f32(h->b, Np, [&](int n) { const int nl = to_log(n); return nl >= 0 ? b[nl] : 0.f; });
+    if (rc) return rc < 0 ? rc : dcvc::E_MEM;
+    *out = h.release();
+    return 0;
+}
+
+void dcvc_conv_destroy(dcvc_conv* h) { delete h; }
+
+int dcvc_conv_forward(const dcvc_conv* h, const void* x0, int64_t ld0, int c0, const void* x1, int64_t ld1, int c1,
+                      int H, int W, const float* quant, void* out, int64_t ldo, void* stream)
+{
+    DCVC_REQUIRE(h && x0 && out, "dcvc_conv_forward: null pointer");
+    DCVC_REQUIRE(H > 0 && W > 0, "dcvc_conv_forward: empty input %dx%d", H, W);
+    DCVC_REQUIRE(c0 % 32 == 0 && c1 % 32 == 0 && c0 + c1 == h->cin_p,
+                 "dcvc_conv_forward: input channels %d+%d do not match the layer (%d physical)", c0, c1, h->cin_p);
+    DCVC_REQUIRE((x1 != nullptr) == (c1 > 0), "dcvc_conv_forward: x1/c1 mismatch");
+    DCVC_REQUIRE(h->epi != DCVC_EPI_BIAS_QUANT || quant != nullptr, "dcvc_conv_forward: quant vector required");
+    const size_t es = dcvc::elem_size(h->dtype);
+    DCVC_REQUIRE(((uintptr_t)x0 % 16) == 0 && (ld0 * es) % 16 == 0 && (c1 == 0 || (((uintptr_t)x1 % 16) == 0 && (ld1 * es) % 16 == 0)),
+                 "dcvc_conv_forward: inputs must be 16-byte aligned");
+    ConvParams cp{};
+    cp.src = SrcPair{x0, (long)ld0, c0, x1, (long)ld1, c1};
+    cp.H = H;
+    cp.W = W;
+    cp.Ho = (H + 2 * h->pad - h->kh) / h->stride + 1;
+    cp.Wo = (W + 2 * h->pad - h->kw) / h->stride + 1;
+    DCVC_REQUIRE(cp.Ho > 0 && cp.Wo > 0, "dcvc_conv_forward: empty output");
+    cp.KH = h->kh;
+    cp.KW = h->kw;
+    cp.stride = h->stride;
+    cp.pad = h->pad;
+    cp.N = h->n_p;
+    cp.n_log = h->cout;
+    cp.cs_p = h->cs_p;
+    cp.w = h->w.p;
+    cp.b = (const float*)h->b.p;
+    cp.q = quant;
+    cp.epi = h->epi;
+    cp.out = out;
+    cp.ldo = ldo;
+    DCVC_REQUIRE(ldo >= (h->epi == DCVC_EPI_SHUFFLE2 ? h->cs_p : h->n_p), "dcvc_conv_forward: output row stride too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (h->dtype == DCVC_F16) return dispatch_conv<half_t, 4>(h, cp, st);
+    return dispatch_conv<float, 2>(h, cp, st);
+}
+
+}  // extern "C"

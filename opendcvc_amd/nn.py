@@ -1,0 +1,228 @@
+"""Host-side layer objects over the C ABI: they own packed device weights (created once) and
+launch the HIP kernels on torch's current stream.  torch is only the container for device
+memory; activations are HWC tensors [H, W, C_phys] (channel counts padded to a multiple of 32,
+DepthConvBlock widths to a multiple of 64, pad channels are exact zeros).
+
+Mirrors the reference's layer vocabulary (src/layers/layers.py): DepthConvBlock, SubpelConv2x,
+ResidualBlockWithStride2, ResidualBlockUpsample, plus plain Conv2d.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DcvcError, check
+
+F16, F32 = _lib.F16, _lib.F32
+
+
+def dtype_code(dt):
+    if dt == torch.float16:
+        return F16
+    if dt == torch.float32:
+        return F32
+    raise DcvcError(f"unsupported dtype {dt}: the HIP path computes in float16 or float32")
+
+
+def cpad(c, m=32):
+    return (c + m - 1) // m * m
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _host(a):
+    a = np.ascontiguousarray(a.detach().cpu().float().numpy() if isinstance(a, torch.Tensor) else a, dtype=np.float32)
+    return a
+
+
+def _hp(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def _geom(x):
+    """(H, W, C, ld) of an HWC tensor/view usable by the kernels."""
+    if x.dim() != 3 or x.stride(2) != 1 or x.stride(0) != x.shape[1] * x.stride(1):
+        raise DcvcError(f"expected an HWC tensor with contiguous channels and uniform row stride, got "
+                        f"shape {tuple(x.shape)} strides {tuple(x.stride())}")
+    return x.shape[0], x.shape[1], x.shape[2], x.stride(1)
+
+
+class Scratch:
+    """Grow-only device scratch per (device, stream): no allocation in the steady state."""
+    _pool = {}
+
+    @classmethod
+    def get(cls, nbytes, device):
+        key = (str(device), torch.cuda.current_stream().cuda_stream)
+        buf = cls._pool.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+            cls._pool[key] = buf
+        return buf
+
+
+class DepthConvBlock:
+    """Fused DepthConvBlock (reference: src/layers/layers.py:65-132, impl.cpp:7-121)."""
+
+    def __init__(self, sd, prefix, dtype, shortcut=False):
+        L = _lib.lib()
+        g = lambda n: _host(sd[prefix + n])
+        self.has_adaptor = (prefix + ".adaptor.weight") in sd
+        w1 = g(".dc.0.weight")
+        self.c = w1.shape[0]
+        wa = g(".adaptor.weight") if self.has_adaptor else None
+        ba = g(".adaptor.bias") if self.has_adaptor else None
+        self.cin = wa.shape[1] if self.has_adaptor else self.c
+        self.c_p = cpad(self.c, 64)
+        self.cin_p = cpad(self.cin, 32) if self.has_adaptor else self.c_p
+        self.dtype = dtype
+        arrs = [wa, ba, w1, g(".dc.0.bias"), g(".dc.2.weight"), g(".dc.2.bias"), g(".dc.3.weight"),
+                g(".dc.3.bias"), g(".ffn.0.weight"), g(".ffn.0.bias"), g(".ffn.2.weight"), g(".ffn.2.bias")]
+        h = ctypes.c_void_p()
+        check(L.dcvc_dcb_create(dtype_code(dtype), self.cin, self.c, int(shortcut), *[_hp(a) for a in arrs],
+                                ctypes.byref(h)), "dcvc_dcb_create")
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _lib.lib().dcvc_dcb_destroy(self.h)
+        except Exception:
+            pass
+
+    def __call__(self, x0, x1=None, quant=None, out=None):
+        """x = concat(x0, x1) along channels; quant: float32 device tensor [C] or None;
+        out: optional HWC view to write into (e.g. a slice of a concat buffer)."""
+        L = _lib.lib()
+        H, W, c0, ld0 = _geom(x0)
+        c1, ld1 = 0, 0
+        if x1 is not None:
+            H1, W1, c1, ld1 = _geom(x1)
+            if (H1, W1) != (H, W):
+                raise DcvcError("concat inputs differ in size")
+        if out is None:
+            out = torch.empty((H, W, self.c_p), dtype=self.dtype, device=x0.device)
+        Ho, Wo, co, ldo = _geom(out)
+        if (Ho, Wo) != (H, W) or co < self.c_p:
+            raise DcvcError(f"output view {tuple(out.shape)} does not fit a {self.c_p}-channel block output")
+        if x0.dtype != self.dtype or out.dtype != self.dtype:
+            raise DcvcError("dtype mismatch between block and tensors")
+        nbytes = L.dcvc_dcb_scratch_bytes(self.h, H, W)
+        scratch = Scratch.get(nbytes, x0.device)
+        check(L.dcvc_dcb_forward(self.h, _p(x0), ld0, c0, _p(x1), ld1, c1, H, W, _p(quant), _p(out), ldo,
+                                 _p(scratch), _stream()), "dcvc_dcb_forward")
+        return out
+
+
+class Conv2d:
+    """Dense conv (1x1 / 3x3 s1,s2 p1 / 2x2 s2) with fused epilogue; reference: nn.Conv2d uses in
+    video_model.py / image_model.py / layers.py and the epilogue kernels of kernel.cu."""
+
+    def __init__(self, sd, prefix, dtype, stride=1, pad=0, epilogue=_lib.EPI_BIAS):
+        L = _lib.lib()
+        w = _host(sd[prefix + ".weight"])
+        b = _host(sd[prefix + ".bias"])
+        self.cout, self.cin, self.kh, self.kw = w.shape
+        self.stride, self.pad, self.epi, self.dtype = stride, pad, epilogue, dtype
+        self.cin_p = cpad(self.cin, 32)
+        if epilogue == _lib.EPI_SHUFFLE2:
+            self.cout_p = cpad(self.cout // 4, 32)     # channels after PixelShuffle(2)
+        else:
+            self.cout_p = cpad(self.cout, 32)
+        h = ctypes.c_void_p()
+        check(L.dcvc_conv_create(dtype_code(dtype), self.cin, self.cout, self.kh, self.kw, stride, pad, epilogue,
+                                 _hp(w), _hp(b), ctypes.byref(h)), "dcvc_conv_create")
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _lib.lib().dcvc_conv_destroy(self.h)
+        except Exception:
+            pass
+
+    def out_hw(self, H, W):
+        Ho = (H + 2 * self.pad - self.kh) // self.stride + 1
+        Wo = (W + 2 * self.pad - self.kw) // self.stride + 1
+        if self.epi == _lib.EPI_SHUFFLE2:
+            return 2 * Ho, 2 * Wo
+        return Ho, Wo
+
+    def __call__(self, x0, x1=None, quant=None, out=None):
+        L = _lib.lib()
+        H, W, c0, ld0 = _geom(x0)
+        c1, ld1 = 0, 0
+        if x1 is not None:
+            _, _, c1, ld1 = _geom(x1)
+        Ho, Wo = self.out_hw(H, W)
+        if out is None:
+            out = torch.empty((Ho, Wo, self.cout_p), dtype=self.dtype, device=x0.device)
+        H2, W2, co, ldo = _geom(out)
+        if (H2, W2) != (Ho, Wo) or co < self.cout_p:
+            raise DcvcError(f"output view {tuple(out.shape)} does not fit conv output {(Ho, Wo, self.cout_p)}")
+        check(L.dcvc_conv_forward(self.h, _p(x0), ld0, c0, _p(x1), ld1, c1, H, W, _p(quant), _p(out), ldo,
+                                  _stream()), "dcvc_conv_forward")
+        return out
+
+
+class SubpelConv2x:
+    """conv + PixelShuffle(2) (reference: layers.py:29-62, SubpelConv2xProxy impl.cpp:123-167)."""
+
+    def __init__(self, sd, prefix, dtype, pad):
+        self.conv = Conv2d(sd, prefix + ".conv.0", dtype, 1, pad, _lib.EPI_SHUFFLE2)
+        self.cout_p = self.conv.cout_p
+
+    def __call__(self, x, out=None):
+        return self.conv(x, out=out)
+
+
+class ResidualBlockWithStride2:
+    """reference: layers.py:135-144"""
+
+    def __init__(self, sd, prefix, dtype):
+        self.down = Conv2d(sd, prefix + ".down", dtype, 2, 0)
+        self.conv = DepthConvBlock(sd, prefix + ".conv", dtype, shortcut=True)
+
+    def __call__(self, x, out=None):
+        return self.conv(self.down(x), out=out)
+
+
+class ResidualBlockUpsample:
+    """reference: layers.py:147-156"""
+
+    def __init__(self, sd, prefix, dtype):
+        self.up = SubpelConv2x(sd, prefix + ".up", dtype, 0)
+        self.conv = DepthConvBlock(sd, prefix + ".conv", dtype, shortcut=True)
+
+    def __call__(self, x, out=None):
+        return self.conv(self.up(x), out=out)
+
+
+# ----------------------------------------------------------------------------- tensor helpers
+
+def to_hwc(x_nchw, c_phys=None):
+    """NCHW torch tensor [1,C,H,W] on the GPU -> HWC [H,W,c_phys] (zero padded), via the HIP kernel."""
+    L = _lib.lib()
+    _, C, H, W = x_nchw.shape
+    cp_ = c_phys or cpad(C)
+    x = x_nchw.contiguous()
+    out = torch.zeros((H, W, cp_), dtype=x.dtype, device=x.device) if cp_ != C else \
+        torch.empty((H, W, cp_), dtype=x.dtype, device=x.device)
+    check(L.dcvc_nchw_to_hwc(dtype_code(x.dtype), _p(x), C, H * W, _p(out), cp_, _stream()), "dcvc_nchw_to_hwc")
+    return out
+
+
+def to_nchw(x_hwc, C=None):
+    L = _lib.lib()
+    H, W, cp_, ld = _geom(x_hwc)
+    C = C or cp_
+    out = torch.empty((1, C, H, W), dtype=x_hwc.dtype, device=x_hwc.device)
+    check(L.dcvc_hwc_to_nchw(dtype_code(x_hwc.dtype), _p(x_hwc), ld, C, H * W, _p(out), _stream()), "dcvc_hwc_to_nchw")
+    return out

@@ -1,0 +1,180 @@
+"""HIP conv kernels (through the C ABI) against the CPU oracle on the same seeded inputs.
+fp32 mode: bit-exact (the kernels use the oracle's fma order on the fp32-input MFMA);
+fp16 mode: fp16 storage / fp32 accumulate, compared with a stated tolerance."""
+import numpy as np
+import pytest
+import torch
+
+import dcvc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+F16_RTOL = 3e-2   # relative to the tensor's RMS: fp16 storage of every intermediate (11-bit mantissa)
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+def make_dcb_weights(rng, prefix, cin, c, adaptor):
+    sd = {}
+
+    def conv(name, co, ci, k=1, gain=1.0):
+        sd[f"{prefix}.{name}.weight"] = (rng.standard_normal((co, ci, k, k)) * gain / np.sqrt(ci * k * k)).astype(np.float32)
+        sd[f"{prefix}.{name}.bias"] = (rng.standard_normal(co) * 0.1).astype(np.float32)
+
+    if adaptor:
+        conv("adaptor", c, cin)
+    conv("dc.0", c, c)
+    sd[f"{prefix}.dc.2.weight"] = (rng.standard_normal((c, 1, 3, 3)) / 3).astype(np.float32)
+    sd[f"{prefix}.dc.2.bias"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
+    conv("dc.3", c, c, gain=0.5)
+    conv("ffn.0", 4 * c, c)
+    conv("ffn.2", c, 2 * c, gain=0.5)
+    return sd
+
+
+def to_dev(x_hwc, cp, dtype):
+    H, W, C = x_hwc.shape
+    t = torch.zeros((H, W, cp), dtype=dtype, device="cuda")
+    t[:, :, :C] = torch.from_numpy(x_hwc).to(dtype)
+    return t
+
+
+def compare(got, ref, dtype, what):
+    if dtype == torch.float32:
+        assert np.array_equal(got, ref), f"{what}: fp32 path not bit-exact, max|d|={np.abs(got - ref).max()}"
+    else:
+        rms = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2))) + 1e-6
+        err = float(np.abs(got.astype(np.float64) - ref).max())
+        assert err <= F16_RTOL * rms * 4, f"{what}: fp16 max err {err} vs rms {rms}"
+
+
+DCB_CASES = [
+    # cin, c, adaptor, shortcut, quant, H, W, split (concat of two sources)
+    (256, 256, False, False, False, 16, 24, None),
+    (256, 256, False, False, True, 13, 21, None),
+    (512, 256, True, False, False, 9, 17, 256),
+    (192, 256, True, False, False, 8, 8, None),
+    (128, 128, False, True, False, 5, 7, None),
+    (368, 368, False, False, True, 10, 11, None),
+    (192, 368, True, False, True, 7, 9, None),
+    (368, 192, True, False, False, 6, 6, None),
+    (256, 320, True, False, False, 8, 10, None),
+    (320, 320, False, False, True, 9, 9, None),
+    (512, 384, True, False, False, 7, 8, 128),
+    (384, 384, False, False, False, 8, 9, None),
+    (512, 512, True, False, False, 6, 10, 256),
+    (512, 512, False, False, False, 5, 9, None),
+    (256, 128, True, False, False, 4, 4, None),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("case", DCB_CASES)
+def test_depth_conv_block(case, dtype):
+    from opendcvc_amd import nn
+    cin, c, adaptor, shortcut, quant, H, W, split = case
+    rng = _rng(100 + DCB_CASES.index(case))
+    sd = make_dcb_weights(rng, "m", cin, c, adaptor)
+    x = rng.standard_normal((H, W, cin)).astype(np.float32)
+    q = rng.uniform(0.5, 1.5, c).astype(np.float32) if quant else None
+    if dtype == torch.float16:   # the oracle sees the same fp16-rounded input
+        x = x.astype(np.float16).astype(np.float32)
+    ref = O.Net(sd).dcb(x, "m", shortcut=shortcut, q=q)
+    blk = nn.DepthConvBlock(sd, "m", dtype, shortcut=shortcut)
+    qd = torch.from_numpy(q).cuda() if quant else None
+    if split:
+        x0 = to_dev(x[:, :, :split], split, dtype)
+        x1 = to_dev(x[:, :, split:], cin - split, dtype)
+        out = blk(x0, x1, quant=qd)
+    else:
+        out = blk(to_dev(x, blk.cin_p, dtype), quant=qd)
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    assert not np.any(got[:, :, c:]), "pad channels must stay zero"
+    compare(got[:, :, :c], ref, dtype, f"dcb {case}")
+
+
+def test_dcb_writes_into_concat_slice():
+    from opendcvc_amd import nn
+    rng = _rng(5)
+    sd = make_dcb_weights(rng, "m", 256, 256, False)
+    x = rng.standard_normal((6, 7, 256)).astype(np.float32)
+    ref = O.Net(sd).dcb(x, "m")
+    blk = nn.DepthConvBlock(sd, "m", torch.float32)
+    buf = torch.full((6, 7, 512), 7.0, device="cuda")
+    blk(to_dev(x, 256, torch.float32), out=buf[:, :, 256:])
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy()
+    assert np.array_equal(got[:, :, 256:], ref) and np.all(got[:, :, :256] == 7.0)
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, epilogue, H, W
+    (256, 256, 1, 1, 0, "quant", 9, 13),
+    (256, 128, 3, 2, 1, "bias", 12, 18),
+    (368, 256, 3, 2, 1, "bias", 8, 10),
+    (128, 1024, 3, 1, 1, "shuffle", 6, 9),
+    (128, 512, 1, 1, 0, "shuffle", 5, 6),
+    (256, 1472, 1, 1, 0, "shuffle", 4, 5),
+    (128, 128, 2, 2, 0, "bias", 8, 12),
+    (256, 256, 2, 2, 0, "bias", 10, 6),
+    (512, 514, 1, 1, 0, "bias", 5, 7),
+    (514, 256, 1, 1, 0, "bias", 5, 7),
+    (320, 192, 1, 1, 0, "bias", 7, 7),
+    (384, 256, 1, 1, 0, "wsilu", 6, 5),
+]
+EPI = {"bias": 0, "quant": 1, "shuffle": 2, "wsilu": 3}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv(case, dtype):
+    from opendcvc_amd import nn
+    cin, cout, k, stride, pad, epi, H, W = case
+    rng = _rng(200 + CONV_CASES.index(case))
+    sd = {"m.weight": (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32),
+          "m.bias": (rng.standard_normal(cout) * 0.1).astype(np.float32)}
+    x = rng.standard_normal((H, W, cin)).astype(np.float32)
+    if dtype == torch.float16:
+        x = x.astype(np.float16).astype(np.float32)
+    q = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    ref = O.Net(sd).conv(x, "m", stride, pad)
+    if epi == "quant":
+        ref = ref * q
+    elif epi == "shuffle":
+        ref = O.pixel_shuffle(ref, 2)
+    elif epi == "wsilu":
+        ref = O.wsilu(ref)
+    conv = nn.Conv2d(sd, "m", dtype, stride, pad, EPI[epi])
+    out = conv(to_dev(x, conv.cin_p, dtype), quant=torch.from_numpy(q).cuda() if epi == "quant" else None)
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    c_log = cout // 4 if epi == "shuffle" else cout
+    assert got.shape[:2] == ref.shape[:2]
+    assert not np.any(got[:, :, c_log:]), "pad channels must stay zero"
+    compare(got[:, :, :c_log], ref, dtype, f"conv {case}")
+
+
+def test_conv_concat_sources():
+    from opendcvc_amd import nn
+    rng = _rng(9)
+    sd = {"m.weight": (rng.standard_normal((128, 512, 1, 1)) / 22).astype(np.float32),
+          "m.bias": rng.standard_normal(128).astype(np.float32)}
+    x = rng.standard_normal((5, 6, 512)).astype(np.float32)
+    ref = O.Net(sd).conv(x, "m")
+    conv = nn.Conv2d(sd, "m", torch.float32)
+    out = conv(to_dev(x[:, :, :128], 128, torch.float32), to_dev(x[:, :, 128:], 384, torch.float32))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_bad_arguments_fail_loudly():
+    from opendcvc_amd import nn
+    from opendcvc_amd._lib import DcvcError
+    rng = _rng(1)
+    sd = make_dcb_weights(rng, "m", 256, 256, False)
+    blk = nn.DepthConvBlock(sd, "m", torch.float32)
+    with pytest.raises(DcvcError):
+        blk(torch.zeros((4, 4, 128), device="cuda"))
