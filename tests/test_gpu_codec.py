@@ -1,0 +1,91 @@
+"""Full DMCI / DMC codecs on the HIP path (through the model API = drop-in seam 1) against
+(a) the CPU oracle on the same seeded weights and frames: fp32 mode must be BIT-EXACT (streams,
+    features, reconstructions);
+(b) the reference's golden records (tests/golden/sequences.json), with the fp32 tolerance of
+    BASELINE.json (PSNR / bpp within 1e-4);
+(c) fp16 mode: encoder/decoder self-consistency and rate/distortion close to the fp32 path."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dcvc_oracle as O
+from opendcvc_amd import weights
+from seq_utils import check_against_record, psnr_of, run_sequence
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_codecs(seed, thres, dtype):
+    from opendcvc_amd.models import DMC, DMCI
+    i_net, p_net = DMCI(), DMC()
+    i_net.load_state_dict({k: torch.from_numpy(v) for k, v in weights.make_state_dict("dmci", seed).items()})
+    p_net.load_state_dict({k: torch.from_numpy(v) for k, v in weights.make_state_dict("dmc", seed).items()})
+    for m in (i_net, p_net):
+        m.to("cuda").eval()
+        m.update(thres)
+        if dtype == torch.float16:
+            m.half()
+    return i_net, p_net
+
+
+def run_hip(rec, dtype, n_frames=None):
+    i_net, p_net = hip_codecs(rec["seed"], rec["thres"], dtype)
+    return run_sequence(i_net, p_net, rec, n_frames,
+                        to_x=lambda a: torch.from_numpy(a).to("cuda", dtype),
+                        to_np=lambda t: t.float().cpu().numpy(),
+                        feature_of=lambda p: p.dpb[0].feature.float().cpu().numpy())
+
+
+def run_oracle(rec, n_frames=None):
+    i_net = O.OracleDMCI(weights.make_state_dict("dmci", rec["seed"]))
+    p_net = O.OracleDMC(weights.make_state_dict("dmc", rec["seed"]))
+    i_net.update(rec["thres"])
+    p_net.update(rec["thres"])
+    return run_sequence(i_net, p_net, rec, n_frames, feature_of=lambda p: p.ref_feature)
+
+
+@pytest.fixture(scope="module")
+def seqs(golden_dir):
+    d = json.load(open(os.path.join(golden_dir, "sequences.json")))
+    d["seq_64"] = json.loads(str(np.load(os.path.join(golden_dir, "seq_64.npz"))["meta"]))
+    return d
+
+
+@pytest.mark.parametrize("name", ["seq_64", "seq_64_two", "seq_80x48", "seq_256"])
+def test_fp32_bit_exact_with_oracle_and_within_tolerance_of_reference(seqs, name):
+    rec = seqs[name]
+    got = run_hip(rec, torch.float32)
+    ora = run_oracle(rec)
+    for fi, (g, o) in enumerate(zip(got, ora)):
+        assert g["bits"] == o["bits"], f"frame {fi}: HIP fp32 stream differs from the oracle"
+        assert np.array_equal(g["x_hat"], o["x_hat"]), f"frame {fi}: reconstruction differs from the oracle"
+        if fi > 0:
+            assert np.array_equal(g["feature"], o["feature"]), f"frame {fi}: encoder feature differs"
+            assert np.array_equal(g["dec_feature"], g["feature"]), f"frame {fi}: enc/dec feature desync"
+    check_against_record(rec, got, min_exact=1.0 if name != "seq_256" else 0.75)
+
+
+def test_fp16_self_consistent_and_close_to_fp32(seqs):
+    rec = seqs["seq_256"]
+    got = run_hip(rec, torch.float16)
+    for fi, g in enumerate(got):
+        if fi > 0:   # decoder reproduces the encoder's reference feature bit for bit
+            assert np.array_equal(g["dec_feature"], g["feature"]), f"frame {fi}: fp16 enc/dec desync"
+        f = rec["frames"][fi]
+        # fp16 storage of every activation: rate within 2 %, PSNR within 0.05 dB of the fp32 reference run
+        assert abs(len(g["bits"]) - f["bytes"]) <= 0.02 * f["bytes"], (fi, len(g["bits"]), f["bytes"])
+        assert abs(psnr_of(rec, fi, g["x_hat"]) - f["psnr"]) < 0.05
+
+
+def test_requires_update_and_cuda():
+    from opendcvc_amd._lib import DcvcError
+    from opendcvc_amd.models import DMCI
+    m = DMCI()
+    with pytest.raises(DcvcError):
+        m.compress(torch.zeros(1, 3, 64, 64), 0)          # cpu model: no fallback
+    m.to("cuda")
+    with pytest.raises(DcvcError):
+        m.compress(torch.zeros(1, 3, 64, 64, device="cuda"), 0)   # update() not called
