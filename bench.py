@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py - DCVC-RT 1080p YUV420 encode+decode throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one frame of a 32-frame-GOP 1080p sequence (configs[1]) ENCODED and then DECODED by the
+HIP path (fp16 storage / fp32 accumulate, like the reference's published numbers), including the
+host rANS coding, with the padded input frames already resident in HBM.  With N > 1 every rank
+codes its own independent stream (weak scaling, no data-path collective; the weights are
+broadcast once from rank 0 over RCCL).  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     dominant kernel (dcb_tail_kernel<f16>, C = 256 at 136x240): algorithmic FLOP per
+               launch / HIP-event time on its stream, against the 2.5 PFLOP/s dense f16 MFMA peak.
+  cpu_baseline the CPU oracle (port of the reference's torch fallback path) timed on the host
+               cores on a bounded sample (one 1080p P frame, encode + decode).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from opendcvc_amd import _lib, weights  # noqa: E402
+from opendcvc_amd import nn as L  # noqa: E402
+from opendcvc_amd.models import DMC, DMCI  # noqa: E402
+from opendcvc_amd.pipeline import SequenceDecoder, SequenceEncoder, use_two_entropy_coders  # noqa: E402
+
+HEIGHT, WIDTH = 1080, 1920
+GOP = 32
+QP = 32
+THRES = 0.12
+MFMA_F16_PEAK_TFLOPS = 2500.0      # dense, MI355X_MICROARCH.md
+# reference README.md:35 (A100, fp16): 125.2 enc fps / 112.8 dec fps -> one frame through both
+BASELINE_ENC_FPS, BASELINE_DEC_FPS = 125.2, 112.8
+
+
+def load_models(dtype, device, world, rank):
+    sds = {}
+    for name in ("dmci", "dmc"):
+        sd = weights.make_state_dict(name, 1234) if rank == 0 else None
+        if world > 1:
+            import torch.distributed as dist
+            spec = weights.arch.spec_for(name).items
+            total = sum(int(np.prod(s)) for _, s, _ in spec)
+            blob = torch.empty(total, dtype=torch.float32, device=device)
+            if rank == 0:
+                blob.copy_(torch.from_numpy(np.concatenate([sd[k].reshape(-1) for k, _, _ in spec])))
+            dist.broadcast(blob, 0)            # one RCCL broadcast of the weight blob over xGMI
+            flat = blob.cpu().numpy()
+            sd, off = {}, 0
+            for k, s, _ in spec:
+                n = int(np.prod(s))
+                sd[k] = flat[off:off + n].reshape(s)
+                off += n
+        sds[name] = sd
+
+    def make(cls, name):
+        m = cls()
+        m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sds[name].items()})
+        m.to(device).eval()
+        m.update(THRES)
+        if dtype == torch.float16:
+            m.half()
+        return m
+    return (make(DMCI, "dmci"), make(DMC, "dmc")), (make(DMCI, "dmci"), make(DMC, "dmc"))
+
+
+def make_frames(seed, dtype, device):
+    pr, pb = DMCI.get_padding_size(HEIGHT, WIDTH, 16)
+    frames = []
+    for fi in range(GOP):
+        x = weights.synthetic_frame_yuv444(HEIGHT, WIDTH, fi, seed)
+        x = np.pad(x, ((0, 0), (0, 0), (0, pb), (0, pr)), mode="edge")
+        frames.append(torch.from_numpy(x).to(device=device, dtype=dtype))
+    return frames
+
+
+def roofline_leg(p_net, device, dtype):
+    """HIP-event timing of the dominant kernel on its own stream."""
+    blk = p_net._layers["fe2"][0]          # DepthConvBlock C=256 at H/8 x W/8
+    H, W, C = (HEIGHT + 7) // 8, WIDTH // 8, 256
+    x = (torch.randn((H, W, C), device=device) * 0.5).to(dtype)
+    out = torch.empty_like(x)
+    lib = _lib.lib()
+    scratch = L.Scratch.get(lib.dcvc_dcb_scratch_bytes(blk.h, H, W), device)
+    head, tail = ctypes.c_float(), ctypes.c_float()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for iters in (5, 30):
+        _lib.check(lib.dcvc_dcb_profile(blk.h, L._p(x), C, C, H, W, L._p(out), C, L._p(scratch), st, iters,
+                                        ctypes.byref(head), ctypes.byref(tail)), "dcvc_dcb_profile")
+    P = H * W
+    flop = 2.0 * P * (7 * C * C + 9 * C)               # W2 + W3(4x) + W4(2x) + depthwise, per launch
+    achieved = flop / (tail.value * 1e-3) / 1e12
+    traffic = None
+    pmc = os.path.join(REPO, "profiles", "pmc_dcb_tail.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {"kernel": "dcb_tail_kernel<f16,MT=4,NTW=4> (C=256, 136x240)", "bound": "mfma",
+            "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
+            "flop_per_launch": flop, "kernel_ms": round(tail.value, 4),
+            "head_kernel_ms": round(head.value, 4)}
+
+
+def cpu_baseline_leg():
+    """The oracle (CPU port of the reference path) on one 1080p P frame, encode + decode."""
+    ncores = min(len(os.sched_getaffinity(0)), 32)
+    os.environ["OMP_NUM_THREADS"] = str(ncores)      # read by libgomp when the oracle library loads
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import dcvc_oracle as O
+    pr, pb = DMCI.get_padding_size(HEIGHT, WIDTH, 16)
+    pad = lambda a: np.pad(a, ((0, 0), (0, 0), (0, pb), (0, pr)), mode="edge")
+    x0 = pad(weights.synthetic_frame_yuv444(HEIGHT, WIDTH, 0, 0))
+    x1 = pad(weights.synthetic_frame_yuv444(HEIGHT, WIDTH, 1, 0))
+    p = O.OracleDMC(weights.make_state_dict("dmc", 1234))
+    p.update(THRES)
+    p.set_use_two_entropy_coders(True)
+    p.clear_dpb()
+    p.add_ref_frame(None, x0)
+    t0 = time.perf_counter()
+    enc = p.compress(x1, QP)
+    t1 = time.perf_counter()
+    p.clear_dpb()
+    p.add_ref_frame(None, x0)
+    p.decompress(enc["bit_stream"], dict(height=HEIGHT, width=WIDTH, ec_part=1, use_ada_i=0), QP)
+    t2 = time.perf_counter()
+    return {"value": round(1.0 / (t2 - t0), 4), "unit": "frames/s", "cores": ncores, "kind": "port",
+            "sample": "one 1080p (1088x1920 padded) P frame, encode %.2f s + decode %.2f s, fp32 C/OpenMP oracle"
+                      % (t1 - t0, t2 - t1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    _lib.require_gpu()
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    dtype = torch.float16
+    torch.set_grad_enabled(False)
+
+    (ie, pe), (idec, pdec) = load_models(dtype, device, world, rank)
+    two = use_two_entropy_coders(HEIGHT, WIDTH)
+    for m in (ie, pe, idec, pdec):
+        m.set_use_two_entropy_coders(two)
+    frames = make_frames(rank, dtype, device)
+    enc = SequenceEncoder(ie, pe, QP, intra_period=GOP, reset_interval=GOP)
+    dec = SequenceDecoder(idec, pdec, HEIGHT, WIDTH, two)
+
+    state = {"i": 0, "t_enc": 0.0, "t_dec": 0.0, "bytes": 0, "n_i": 0}
+
+    def step(timed):
+        x = frames[state["i"] % GOP]
+        state["i"] += 1
+        t0 = time.perf_counter()
+        pkt = enc.encode(x)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        x_hat = dec.decode(pkt)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if timed:
+            state["t_enc"] += t1 - t0
+            state["t_dec"] += t2 - t1
+            state["bytes"] += len(pkt.bit_stream)
+            state["n_i"] += int(pkt.is_i)
+        return x_hat
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        K, N = args.steps, world
+        value = N * K / elapsed
+        base = 1.0 / (1.0 / BASELINE_ENC_FPS + 1.0 / BASELINE_DEC_FPS)
+        out = {
+            "metric": "1080p YUV420 encode+decode FPS (frames/s through encode AND decode, whole job)",
+            "value": round(value, 3), "unit": "frames/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": round(value / N / base, 4), "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "DCVC-RT inter-coding, 1080p YUV420 32-frame GOP, single q (qp 32), "
+                                   "one stream per MI355X (BASELINE.json configs[1])",
+                       "frame": "1920x1080 padded to 1920x1088", "intra_period": GOP, "i_frames_timed": state["n_i"],
+                       "entropy_coders": 2 if two else 1, "force_zero_thres": THRES,
+                       "weights": "synthetic seed 1234 (opendcvc_amd/weights.py)",
+                       "baseline_note": "vs_baseline = per-GPU value / (1/(1/125.2+1/112.8)) fps, reference README A100 fp16"},
+            "enc_fps_per_gpu": round(K / state["t_enc"], 2), "dec_fps_per_gpu": round(K / state["t_dec"], 2),
+            "bpp": round(state["bytes"] * 8.0 / (K * HEIGHT * WIDTH), 5),
+        }
+        out["roofline"] = roofline_leg(pe, device, dtype)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_leg()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,11 @@ int dcvc_dcb_forward(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, con
                      int64_t ld1, int c1, int H, int W, const float* quant, void* out, int64_t ldo,
                      void* scratch, void* stream);
 
+/* Measurement aid (bench.py roofline leg): runs the block `iters` times on `stream` with HIP events
+ * recorded on that stream around each of its two kernels; returns the mean durations in ms. */
+int dcvc_dcb_profile(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, int H, int W, void* out,
+                     int64_t ldo, void* scratch, void* stream, int iters, float* head_ms, float* tail_ms);
+
 /* ------------------------------------------------------------------------------------------
  * Dense convolutions (implicit GEMM): 1x1, 3x3 (stride 1 or 2, pad 1), 2x2 stride 2.
  * Replaces: the at::conv2d calls of impl.cpp:61-80,133,148, video_model.py:63,127,162 and the

@@ -505,7 +505,7 @@ int set_lds(K kernel, size_t bytes)
 
 template <typename T, int MT, int NTW>
 int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float* quant, void* out, int64_t ldo,
-               void* scratch, hipStream_t st)
+               void* scratch, hipStream_t st, hipEvent_t* ev = nullptr)
 {
     const int C = h->c_p;
     const int grid = ((H + Tile<MT>::TH - 1) / Tile<MT>::TH) * ((W + Tile<MT>::TW - 1) / Tile<MT>::TW);
@@ -526,6 +526,7 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     hp.a_out = a_buf;
     hp.lda = C;
     const int kin = src.c0 + src.c1;
+    if (ev) DCVC_HIP(hipEventRecord(ev[0], st));
     if (h->adapt) {
         const size_t lds = head_lds<T, MT>(kin, C, true);
         int rc = set_lds(dcb_head_kernel<T, MT, NTW, true>, lds);
@@ -538,6 +539,7 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         hipLaunchKernelGGL((dcb_head_kernel<T, MT, NTW, false>), dim3(grid), dim3(NTHREADS), lds, st, hp);
     }
     DCVC_LAUNCH_CHECK();
+    if (ev) DCVC_HIP(hipEventRecord(ev[1], st));
     TailParams tp{};
     tp.a = a_buf;
     tp.lda = C;
@@ -564,20 +566,21 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     if (rc) return rc;
     hipLaunchKernelGGL((dcb_tail_kernel<T, MT, NTW>), dim3(grid), dim3(NTHREADS), lds, st, tp);
     DCVC_LAUNCH_CHECK();
+    if (ev) DCVC_HIP(hipEventRecord(ev[2], st));
     return 0;
 }
 
 template <typename T, int MT>
 int dispatch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float* quant, void* out, int64_t ldo,
-                 void* scratch, hipStream_t st)
+                 void* scratch, hipStream_t st, hipEvent_t* ev = nullptr)
 {
     switch (h->c_p / 64) {
-    case 2: return launch_dcb<T, MT, 2>(h, src, H, W, quant, out, ldo, scratch, st);
-    case 3: return launch_dcb<T, MT, 3>(h, src, H, W, quant, out, ldo, scratch, st);
-    case 4: return launch_dcb<T, MT, 4>(h, src, H, W, quant, out, ldo, scratch, st);
-    case 5: return launch_dcb<T, MT, 5>(h, src, H, W, quant, out, ldo, scratch, st);
-    case 6: return launch_dcb<T, MT, 6>(h, src, H, W, quant, out, ldo, scratch, st);
-    case 8: return launch_dcb<T, MT, 8>(h, src, H, W, quant, out, ldo, scratch, st);
+    case 2: return launch_dcb<T, MT, 2>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+    case 3: return launch_dcb<T, MT, 3>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+    case 4: return launch_dcb<T, MT, 4>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+    case 5: return launch_dcb<T, MT, 5>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+    case 6: return launch_dcb<T, MT, 6>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+    case 8: return launch_dcb<T, MT, 8>(h, src, H, W, quant, out, ldo, scratch, st, ev);
     default: dcvc::set_error("DepthConvBlock width %d not instantiated", h->c_p); return dcvc::E_ARG;
     }
 }
@@ -673,6 +676,36 @@ int dcvc_dcb_forward(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, con
     hipStream_t st = (hipStream_t)stream;
     if (h->dtype == DCVC_F16) return dispatch_dcb<half_t, 4>(h, src, H, W, quant, out, ldo, scratch, st);
     return dispatch_dcb<float, 2>(h, src, H, W, quant, out, ldo, scratch, st);
+}
+
+int dcvc_dcb_profile(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, int H, int W, void* out, int64_t ldo,
+                     void* scratch, void* stream, int iters, float* head_ms, float* tail_ms)
+{
+    DCVC_REQUIRE(h && x0 && out && scratch && head_ms && tail_ms && iters > 0, "dcvc_dcb_profile: bad arguments");
+    DCVC_REQUIRE(c0 == h->cin_p && ld0 >= c0 && ldo >= h->c_p, "dcvc_dcb_profile: shape mismatch");
+    SrcPair src{x0, (long)ld0, c0, nullptr, 0, 0};
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev((size_t)iters * 3);
+    for (auto& e : ev) DCVC_HIP(hipEventCreate(&e));
+    int rc = 0;
+    for (int i = 0; i < iters && rc == 0; ++i)
+        rc = h->dtype == DCVC_F16 ? dispatch_dcb<half_t, 4>(h, src, H, W, nullptr, out, ldo, scratch, st, &ev[3 * i])
+                                  : dispatch_dcb<float, 2>(h, src, H, W, nullptr, out, ldo, scratch, st, &ev[3 * i]);
+    if (rc == 0) {
+        DCVC_HIP(hipStreamSynchronize(st));
+        double th = 0, tt = 0;
+        for (int i = 0; i < iters; ++i) {
+            float a = 0, b = 0;
+            DCVC_HIP(hipEventElapsedTime(&a, ev[3 * i], ev[3 * i + 1]));
+            DCVC_HIP(hipEventElapsedTime(&b, ev[3 * i + 1], ev[3 * i + 2]));
+            th += a;
+            tt += b;
+        }
+        *head_ms = (float)(th / iters);
+        *tail_ms = (float)(tt / iters);
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
 }
 
 int dcvc_conv_create(int dtype, int cin, int cout, int kh, int kw, int stride, int pad, int epilogue,
