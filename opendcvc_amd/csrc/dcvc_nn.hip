@@ -2,6 +2,7 @@
 // (2 kernels instead of the reference's 8 launches, impl.cpp:53-121) and implicit-GEMM dense
 // convolutions (1x1, 3x3 s1/s2, 2x2 s2) with fused bias / quant / PixelShuffle(2) / WSiLU epilogues.
 // Decomposition and operand layouts: gemm_core.hpp.  C ABI: include/dcvc_amd.h.
+#include <cstdlib>
 #include <functional>
 #include <memory>
 #include <vector>
@@ -14,12 +15,17 @@ namespace {
 using dcvc::round_up;
 
 // ------------------------------------------------------------------------------------------
-// tile geometry: M = 16*MT pixels arranged TH x 8
+// tile geometry: a workgroup owns M = 16*MT pixels arranged TH x TW
 template <int MT>
 struct Tile {
     static constexpr int M = 16 * MT;
-    static constexpr int TW = 8;
+    static constexpr int TW = MT >= 8 ? 16 : 8;
     static constexpr int TH = M / TW;
+};
+
+template <typename T>
+struct Pf {   // weight prefetch depth (reduction groups in flight per wave)
+    static constexpr int value = sizeof(T) == 2 ? 3 : 2;
 };
 
 struct SrcPair {   // channel-concat of up to two HWC sources
@@ -35,7 +41,7 @@ struct SrcPair {   // channel-concat of up to two HWC sources
 template <typename T>
 __device__ __forceinline__ Vec16 load_src(const SrcPair& s, long pix, int c, bool valid)
 {
-    Vec16 v{{0u, 0u, 0u, 0u}};
+    Vec16 v = VEC16_ZERO;
     if (valid) {
         if (c < s.c0)
             v = *reinterpret_cast<const Vec16*>(reinterpret_cast<const T*>(s.x0) + pix * s.ld0 + c);
@@ -44,6 +50,8 @@ __device__ __forceinline__ Vec16 load_src(const SrcPair& s, long pix, int c, boo
     }
     return v;
 }
+
+__device__ __forceinline__ floatx4 load_f4(const float* p) { return *reinterpret_cast<const floatx4*>(p); }
 
 // ------------------------------------------------------------------------------------------
 // DepthConvBlock, first kernel:  x -> [x' = adaptor(x)] -> a = wsilu(conv1(x') + b1)
@@ -65,22 +73,23 @@ __global__ __launch_bounds__(NTHREADS) void dcb_head_kernel(HeadParams p)
 {
     using TR = Traits<T>;
     using frag_t = typename TR::frag_t;
-    constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH, V = TR::kVec, PF = Pf<T>::value;
+    extern __shared__ __attribute__((aligned(32))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Kin = p.src.c0 + p.src.c1;
-    const int ldx = Kin + TR::kPad;
-    const int ldy = p.C + TR::kPad;
+    const int C = p.C;
+    const int ldx = (Kin > C ? Kin : C) + TR::kPad;   // bufX is reused to stage the output tile
+    const int ldy = C + TR::kPad;
     T* bufX = reinterpret_cast<T*>(smem);
     T* bufY = bufX + M * ldx;
 
     const int tiles_x = (p.W + TW - 1) / TW;
     const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
 
-    {   // stage the input tile
-        const int G = Kin / TR::kVec;
+    {   // stage the input tile (coalesced 16-byte loads)
+        const int G = Kin / V;
         for (int it = tid; it < M * G; it += NTHREADS) {
-            const int m = it / G, c = (it - m * G) * TR::kVec;
+            const int m = it / G, c = (it - m * G) * V;
             const int y = ty0 + m / TW, x = tx0 + m % TW;
             const bool valid = (y < p.H) && (x < p.W);
             lds_store_vec<T>(bufX, ldx, m, c, load_src<T>(p.src, (long)y * p.W + x, c, valid));
@@ -91,50 +100,56 @@ __global__ __launch_bounds__(NTHREADS) void dcb_head_kernel(HeadParams p)
     int tiles[NTW];
 #pragma unroll
     for (int i = 0; i < NTW; ++i) tiles[i] = wave + NWAVE * i;
-    const int cq = lane & 15, rq = (lane >> 4) * 4;
+    const int pl = lane & 15, cq = (lane >> 4) * 4;
     floatx4 acc[MT][NTW];
+    const int GC = C / V;
 
     if (ADAPT) {
         zero_acc(acc);
-        gemm_acc<T, MT, NTW>(acc, bufX, ldx, Kin / KG, reinterpret_cast<const frag_t*>(p.wa), Kin / KG, 0, tiles, lane);
+        gemm_acc<T, MT, NTW, PF>(acc, bufX, ldx, Kin / KG, reinterpret_cast<const frag_t*>(p.wa), Kin / KG, 0, tiles, lane);
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
-            const int col = tiles[i] * 16 + cq;
-            const float bias = p.ba[col];
+            const int ch0 = tiles[i] * 16 + cq;
+            const floatx4 bias = load_f4(p.ba + ch0);
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = m * 16 + rq + r;
-                    const int y = ty0 + row / TW, x = tx0 + row % TW;
-                    const T v = TR::from_f(acc[m][i][r] + bias);
-                    bufY[row * ldy + TR::perm(col)] = v;
-                    if (y < p.H && x < p.W)
-                        reinterpret_cast<T*>(p.ident)[((long)y * p.W + x) * p.ldi + col] = v;
-                }
+            for (int m = 0; m < MT; ++m) lds_store_quad<T>(bufY, ldy, m * 16 + pl, ch0, acc[m][i] + bias);
         }
         __syncthreads();
+        // x' is the block's identity branch: write it out with coalesced 16-byte stores
+        for (int it = tid; it < M * GC; it += NTHREADS) {
+            const int m = it / GC, c = (it - m * GC) * V;
+            const int y = ty0 + m / TW, x = tx0 + m % TW;
+            if (y < p.H && x < p.W)
+                *reinterpret_cast<Vec16*>(reinterpret_cast<T*>(p.ident) + ((long)y * p.W + x) * p.ldi + c) =
+                    lds_load_vec<T>(bufY, ldy, m, c);
+        }
     }
 
     zero_acc(acc);
     if (ADAPT)
-        gemm_acc<T, MT, NTW>(acc, bufY, ldy, p.C / KG, reinterpret_cast<const frag_t*>(p.w1), p.C / KG, 0, tiles, lane);
+        gemm_acc<T, MT, NTW, PF>(acc, bufY, ldy, C / KG, reinterpret_cast<const frag_t*>(p.w1), C / KG, 0, tiles, lane);
     else
-        gemm_acc<T, MT, NTW>(acc, bufX, ldx, Kin / KG, reinterpret_cast<const frag_t*>(p.w1), Kin / KG, 0, tiles, lane);
+        gemm_acc<T, MT, NTW, PF>(acc, bufX, ldx, Kin / KG, reinterpret_cast<const frag_t*>(p.w1), Kin / KG, 0, tiles, lane);
+    if (!ADAPT) __syncthreads();   // bufX is still being read as the GEMM operand by other waves
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        const int col = tiles[i] * 16 + cq;
-        const float bias = p.b1[col];
+        const int ch0 = tiles[i] * 16 + cq;
+        const floatx4 bias = load_f4(p.b1 + ch0);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+            floatx4 v = acc[m][i] + bias;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m * 16 + rq + r;
-                const int y = ty0 + row / TW, x = tx0 + row % TW;
-                if (y < p.H && x < p.W)
-                    reinterpret_cast<T*>(p.a_out)[((long)y * p.W + x) * p.lda + col] =
-                        TR::from_f(dcvc_wsiluf(acc[m][i][r] + bias));
-            }
+            for (int r = 0; r < 4; ++r) v[r] = TR::wsilu(v[r]);
+            lds_store_quad<T>(bufX, ldx, m * 16 + pl, ch0, v);
+        }
+    }
+    __syncthreads();
+    for (int it = tid; it < M * GC; it += NTHREADS) {
+        const int m = it / GC, c = (it - m * GC) * V;
+        const int y = ty0 + m / TW, x = tx0 + m % TW;
+        if (y < p.H && x < p.W)
+            *reinterpret_cast<Vec16*>(reinterpret_cast<T*>(p.a_out) + ((long)y * p.W + x) * p.lda + c) =
+                lds_load_vec<T>(bufX, ldx, m, c);
     }
 }
 
@@ -160,21 +175,45 @@ struct TailParams {
     const float* q;      // device, c_log entries, or NULL
     void* out;
     long ldo;
+    int ablate;          // debug: bit0 skip dw, bit1 skip GEMM2, bit2 skip FFN GEMM3, bit3 skip FFN GEMM4
+};
+
+constexpr int DW_SLAB = 64;   // channels per depthwise slab staged in LDS (with its 1-pixel halo)
+
+template <int MT, int NTW>
+struct TailCfg {   // small blocks run two workgroups per CU (<= 256 VGPRs): shallower prefetch, narrower FFN chunk
+    static constexpr bool two_per_cu = (MT <= 4 && NTW <= 4);
+    static constexpr int NTV = two_per_cu ? 1 : 2;
+};
+
+template <typename T, int MT, int NTV>
+struct TailLds {
+    using TR = Traits<T>;
+    static constexpr int M = Tile<MT>::M;
+    static constexpr int VC = NWAVE * NTV * 16;
+    static constexpr int HALO = (Tile<MT>::TH + 2) * (Tile<MT>::TW + 2);
+    static constexpr int lds_slab = DW_SLAB + TR::kPad;
+    static constexpr int ldv = VC + TR::kPad;
+    static constexpr size_t v_elems = (size_t)M * ldv > (size_t)HALO * lds_slab ? (size_t)M * ldv : (size_t)HALO * lds_slab;
+    static size_t bytes(int C) { return ((size_t)M * (C + TR::kPad) + v_elems) * sizeof(T); }
 };
 
 template <typename T, int MT, int NTW>
-__global__ __launch_bounds__(NTHREADS) void dcb_tail_kernel(TailParams p)
+__global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) void dcb_tail_kernel(TailParams p)
 {
     using TR = Traits<T>;
     using frag_t = typename TR::frag_t;
-    constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH;
-    constexpr int NTV = 2;                        // v tiles per wave per chunk
-    constexpr int VC = NWAVE * NTV * 16;          // 128 v columns per chunk
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NTV = TailCfg<MT, NTW>::NTV;    // v tiles per wave per chunk
+    using LD = TailLds<T, MT, NTV>;
+    constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH, V = TR::kVec;
+    constexpr int PF = TailCfg<MT, NTW>::two_per_cu ? 2 : Pf<T>::value;
+    constexpr int VC = NWAVE * NTV * 16;          // v columns per chunk
+    static_assert(VC == LD::VC, "chunk width");
+    extern __shared__ __attribute__((aligned(32))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = p.C;
     const int ldx = C + TR::kPad;
-    constexpr int ldv = VC + TR::kPad;
+    constexpr int ldv = LD::ldv;
     T* bufX = reinterpret_cast<T*>(smem);
     T* bufV = bufX + M * ldx;
 
@@ -182,65 +221,97 @@ __global__ __launch_bounds__(NTHREADS) void dcb_tail_kernel(TailParams p)
     const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
     const T* a = reinterpret_cast<const T*>(p.a);
     const T* ident = reinterpret_cast<const T*>(p.ident);
+    const int GC = C / V;
 
-    {   // depthwise 3x3 (zero padding) of the activation, taps in (ky,kx) order, + bias
-        constexpr int V = TR::kVec;
-        const int G = C / V;
+    {   // depthwise 3x3 (zero padding), taps in (ky,kx) order, + bias.  The activation tile and its
+        // 1-pixel halo go through LDS one 64-channel slab at a time (each input element is fetched
+        // from L2 1.4-1.6x instead of 9x); the next slab is prefetched into registers meanwhile.
+        constexpr int HW_ = TW + 2, HALO = LD::HALO, GS = DW_SLAB / V, lds_s = LD::lds_slab;
+        constexpr int NLD = (HALO * GS + NTHREADS - 1) / NTHREADS;
         const T* wd = reinterpret_cast<const T*>(p.wd);
-        for (int it = tid; it < M * G; it += NTHREADS) {
-            const int m = it / G, c = (it - m * G) * V;
-            const int y = ty0 + m / TW, x = tx0 + m % TW;
-            float s[V];
+        const int nslab = C / DW_SLAB;
+        Vec16 pre[NLD];
+        auto fetch = [&](int slab) {
 #pragma unroll
-            for (int j = 0; j < V; ++j) s[j] = 0.f;
-            if (y < p.H && x < p.W) {
+            for (int k = 0; k < NLD; ++k) {
+                const int it = tid + k * NTHREADS;
+                Vec16 v = VEC16_ZERO;
+                if (it < HALO * GS) {
+                    const int hp = it / GS, c = slab * DW_SLAB + (it - hp * GS) * V;
+                    const int y = ty0 - 1 + hp / HW_, x = tx0 - 1 + hp % HW_;
+                    if (y >= 0 && y < p.H && x >= 0 && x < p.W && !(p.ablate & 1))
+                        v = *reinterpret_cast<const Vec16*>(a + ((long)y * p.W + x) * p.lda + c);
+                }
+                pre[k] = v;
+            }
+        };
+        fetch(0);
+        for (int slab = 0; slab < nslab; ++slab) {
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int iy = y + ky - 1;
-                    if (iy < 0 || iy >= p.H) continue;
+            for (int k = 0; k < NLD; ++k) {
+                const int it = tid + k * NTHREADS;
+                if (it < HALO * GS) {
+                    const int hp = it / GS, cs = (it - hp * GS) * V;
+                    *reinterpret_cast<Vec16*>(bufV + hp * lds_s + cs) = pre[k];   // natural order inside the slab
+                }
+            }
+            __syncthreads();
+            if (slab + 1 < nslab) fetch(slab + 1);
+            for (int it = tid; it < M * GS; it += NTHREADS) {
+                const int m = it / GS, cs = (it - m * GS) * V;
+                const int c = slab * DW_SLAB + cs;
+                const int my = m / TW, mx = m % TW;
+                float s[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) s[j] = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const int ix = x + kx - 1;
-                        if (ix < 0 || ix >= p.W) continue;
                         float av[V], wv[V];
-                        unpack16<T>(*reinterpret_cast<const Vec16*>(a + ((long)iy * p.W + ix) * p.lda + c), av);
+                        unpack16<T>(*reinterpret_cast<const Vec16*>(bufV + ((my + ky) * HW_ + mx + kx) * lds_s + cs), av);
                         unpack16<T>(*reinterpret_cast<const Vec16*>(wd + (ky * 3 + kx) * C + c), wv);
 #pragma unroll
                         for (int j = 0; j < V; ++j) s[j] = DCVC_FMAF(av[j], wv[j], s[j]);
                     }
-                }
 #pragma unroll
                 for (int j = 0; j < V; ++j) s[j] = s[j] + p.bd[c + j];
+                lds_store_vec<T>(bufX, ldx, m, c, pack16<T>(s));
             }
-#pragma unroll
-            for (int j = 0; j < V; ++j) bufX[m * ldx + TR::perm(c + j)] = TR::from_f(s[j]);
+            __syncthreads();
         }
     }
-    __syncthreads();
 
     int tiles[NTW];
 #pragma unroll
     for (int i = 0; i < NTW; ++i) tiles[i] = wave + NWAVE * i;
-    const int cq = lane & 15, rq = (lane >> 4) * 4;
+    const int pl = lane & 15, cq = (lane >> 4) * 4;
 
     floatx4 acc[MT][NTW];
     zero_acc(acc);
-    gemm_acc<T, MT, NTW>(acc, bufX, ldx, C / KG, reinterpret_cast<const frag_t*>(p.w2), C / KG, 0, tiles, lane);
+    if (!(p.ablate & 2))
+        gemm_acc<T, MT, NTW, PF>(acc, bufX, ldx, C / KG, reinterpret_cast<const frag_t*>(p.w2), C / KG, 0, tiles, lane);
     __syncthreads();   // every wave has finished reading d
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        const int col = tiles[i] * 16 + cq;
-        const float bias = p.b2[col];
+        const int ch0 = tiles[i] * 16 + cq;
+        const floatx4 bias = load_f4(p.b2 + ch0);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) lds_store_quad<T>(bufX, ldx, m * 16 + pl, ch0, acc[m][i] + bias);
+    }
+    __syncthreads();
+    // o = (W2 d + b2) + x'   (identity added with coalesced 16-byte global loads)
+    for (int it = tid; it < M * GC; it += NTHREADS) {
+        const int m = it / GC, c = (it - m * GC) * V;
+        const int y = ty0 + m / TW, x = tx0 + m % TW;
+        if (y < p.H && x < p.W) {
+            float o[V], id[V];
+            unpack16<T>(lds_load_vec<T>(bufX, ldx, m, c), o);
+            unpack16<T>(*reinterpret_cast<const Vec16*>(ident + ((long)y * p.W + x) * p.ldi + c), id);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m * 16 + rq + r;
-                const int y = ty0 + row / TW, x = tx0 + row % TW;
-                float idv = 0.f;
-                if (y < p.H && x < p.W) idv = TR::to_f(ident[((long)y * p.W + x) * p.ldi + col]);
-                bufX[row * ldx + TR::perm(col)] = TR::from_f((acc[m][i][r] + bias) + idv);
-            }
+            for (int j = 0; j < V; ++j) o[j] = o[j] + id[j];
+            lds_store_vec<T>(bufX, ldx, m, c, pack16<T>(o));
+        }
     }
     __syncthreads();
 
@@ -257,47 +328,61 @@ __global__ __launch_bounds__(NTHREADS) void dcb_tail_kernel(TailParams p)
             ut[j] = ch * NWAVE * NTV + wave * NTV + j;
             ut[j + NTV] = ut[j] + vtiles;
         }
-        gemm_acc<T, MT, 2 * NTV>(u, bufX, ldx, C / KG, reinterpret_cast<const frag_t*>(p.w3), C / KG, 0, ut, lane);
+        if (!(p.ablate & 4))
+            gemm_acc<T, MT, 2 * NTV, PF>(u, bufX, ldx, C / KG, reinterpret_cast<const frag_t*>(p.w3), C / KG, 0, ut, lane);
 #pragma unroll
         for (int j = 0; j < NTV; ++j) {
-            const int vcol = ut[j] * 16 + cq;
-            const float blo = p.b3[vcol], bhi = p.b3[vcol + 2 * C];
-            const int lcol = (wave * NTV + j) * 16 + cq;
+            const int vch0 = ut[j] * 16 + cq;
+            const floatx4 blo = load_f4(p.b3 + vch0), bhi = load_f4(p.b3 + vch0 + 2 * C);
+            const int lch0 = (wave * NTV + j) * 16 + cq;
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m) {
+                const floatx4 lo = u[m][j] + blo, hi = u[m][j + NTV] + bhi;
+                floatx4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = m * 16 + rq + r;
-                    const float v = dcvc_wsiluf(u[m][j][r] + blo) + dcvc_wsiluf(u[m][j + NTV][r] + bhi);
-                    bufV[row * ldv + TR::perm(lcol)] = TR::from_f(v);
-                }
+                for (int r = 0; r < 4; ++r) v[r] = TR::wsilu(lo[r]) + TR::wsilu(hi[r]);
+                lds_store_quad<T>(bufV, ldv, m * 16 + pl, lch0, v);
+            }
         }
         __syncthreads();
-        gemm_acc<T, MT, NTW>(acc, bufV, ldv, VC / KG, reinterpret_cast<const frag_t*>(p.w4), 2 * C / KG,
-                             ch * (VC / KG), tiles, lane);
+        if (!(p.ablate & 8))
+            gemm_acc<T, MT, NTW, PF>(acc, bufV, ldv, VC / KG, reinterpret_cast<const frag_t*>(p.w4), 2 * C / KG,
+                                     ch * (VC / KG), tiles, lane);
         __syncthreads();
     }
 
-    T* out = reinterpret_cast<T*>(p.out);
+    // r = (W4 v + b4) + o, accumulated in place in LDS (each element is owned by one lane)
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        const int col = tiles[i] * 16 + cq;
-        const float bias = p.b4[col];
-        const float qv = (p.q != nullptr && col < p.c_log) ? p.q[col] : 1.0f;
+        const int ch0 = tiles[i] * 16 + cq;
+        const floatx4 bias = load_f4(p.b4 + ch0);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+            const floatx4 o = lds_load_quad<T>(bufX, ldx, m * 16 + pl, ch0);
+            lds_store_quad<T>(bufX, ldx, m * 16 + pl, ch0, (acc[m][i] + bias) + o);
+        }
+    }
+    __syncthreads();
+    T* out = reinterpret_cast<T*>(p.out);
+    for (int it = tid; it < M * GC; it += NTHREADS) {
+        const int m = it / GC, c = (it - m * GC) * V;
+        const int y = ty0 + m / TW, x = tx0 + m % TW;
+        if (y < p.H && x < p.W) {
+            const long pix = (long)y * p.W + x;
+            float r[V];
+            unpack16<T>(lds_load_vec<T>(bufX, ldx, m, c), r);
+            if (p.shortcut) {
+                float id[V];
+                unpack16<T>(*reinterpret_cast<const Vec16*>(ident + pix * p.ldi + c), id);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m * 16 + rq + r;
-                const int y = ty0 + row / TW, x = tx0 + row % TW;
-                if (y < p.H && x < p.W) {
-                    const long pix = (long)y * p.W + x;
-                    float v = (acc[m][i][r] + bias) + TR::to_f(bufX[row * ldx + TR::perm(col)]);
-                    if (p.shortcut) v = v + TR::to_f(ident[pix * p.ldi + col]);
-                    if (p.q != nullptr) v = v * qv;
-                    out[pix * p.ldo + col] = TR::from_f(v);
-                }
+                for (int j = 0; j < V; ++j) r[j] = r[j] + id[j];
             }
+            if (p.q != nullptr) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) r[j] = r[j] * ((c + j) < p.c_log ? p.q[c + j] : 1.0f);
+            }
+            *reinterpret_cast<Vec16*>(out + pix * p.ldo + c) = pack16<T>(r);
+        }
     }
 }
 
@@ -321,8 +406,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvParams p)
 {
     using TR = Traits<T>;
     using frag_t = typename TR::frag_t;
-    constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH, PF = Pf<T>::value;
+    extern __shared__ __attribute__((aligned(32))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Kin = p.src.c0 + p.src.c1;
     const int ldx = Kin + TR::kPad;
@@ -331,7 +416,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvParams p)
     const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
     const int taps = p.KH * p.KW, kgin = Kin / KG, ntiles = p.N / 16;
     const int passes = (ntiles + NWAVE * NTW - 1) / (NWAVE * NTW);
-    const int cq = lane & 15, rq = (lane >> 4) * 4;
+    const int pl = lane & 15, cq = (lane >> 4) * 4;
     const int G = Kin / TR::kVec;
     T* out = reinterpret_cast<T*>(p.out);
 
@@ -362,44 +447,49 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvParams p)
         floatx4 acc[MT][NTW];
         zero_acc(acc);
         if (taps == 1) {
-            gemm_acc<T, MT, NTW>(acc, bufX, ldx, kgin, reinterpret_cast<const frag_t*>(p.w), kgin, 0, tiles, lane);
+            gemm_acc<T, MT, NTW, PF>(acc, bufX, ldx, kgin, reinterpret_cast<const frag_t*>(p.w), kgin, 0, tiles, lane);
         } else {
             for (int tap = 0; tap < taps; ++tap) {
                 __syncthreads();
                 stage(tap);
                 __syncthreads();
-                gemm_acc<T, MT, NTW>(acc, bufX, ldx, kgin, reinterpret_cast<const frag_t*>(p.w), taps * kgin,
-                                     tap * kgin, tiles, lane);
+                gemm_acc<T, MT, NTW, PF>(acc, bufX, ldx, kgin, reinterpret_cast<const frag_t*>(p.w), taps * kgin,
+                                         tap * kgin, tiles, lane);
             }
         }
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             if (!tvalid[i]) continue;
-            const int col = tiles[i] * 16 + cq;
-            const float bias = p.b[col];
-            const float qv = (p.epi == DCVC_EPI_BIAS_QUANT && col < p.n_log) ? p.q[col] : 1.0f;
-            int sdy = 0, sdx = 0, scol = col;
+            const int ch0 = tiles[i] * 16 + cq;
+            const floatx4 bias = load_f4(p.b + ch0);
+            floatx4 qv = {1.f, 1.f, 1.f, 1.f};
+            if (p.epi == DCVC_EPI_BIAS_QUANT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qv[r] = (ch0 + r) < p.n_log ? p.q[ch0 + r] : 1.0f;
+            }
+            int sdy = 0, sdx = 0, sch0 = ch0;
             if (p.epi == DCVC_EPI_SHUFFLE2) {
-                const int s = col / p.cs_p;
-                scol = col - s * p.cs_p;
+                const int s = ch0 / p.cs_p;
+                sch0 = ch0 - s * p.cs_p;
                 sdy = s >> 1;
                 sdx = s & 1;
             }
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m) {
+                const int row = m * 16 + pl;
+                const int oy = ty0 + row / TW, ox = tx0 + row % TW;
+                if (oy >= p.Ho || ox >= p.Wo) continue;
+                floatx4 v = acc[m][i] + bias;
+                if (p.epi == DCVC_EPI_BIAS_QUANT) v = v * qv;
+                if (p.epi == DCVC_EPI_WSILU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = m * 16 + rq + r;
-                    const int oy = ty0 + row / TW, ox = tx0 + row % TW;
-                    if (oy >= p.Ho || ox >= p.Wo) continue;
-                    float v = acc[m][i][r] + bias;
-                    if (p.epi == DCVC_EPI_BIAS_QUANT) v = v * qv;
-                    if (p.epi == DCVC_EPI_WSILU) v = dcvc_wsiluf(v);
-                    if (p.epi == DCVC_EPI_SHUFFLE2)
-                        out[((long)(2 * oy + sdy) * (2 * p.Wo) + (2 * ox + sdx)) * p.ldo + scol] = TR::from_f(v);
-                    else
-                        out[((long)oy * p.Wo + ox) * p.ldo + col] = TR::from_f(v);
+                    for (int r = 0; r < 4; ++r) v[r] = TR::wsilu(v[r]);
                 }
+                if (p.epi == DCVC_EPI_SHUFFLE2)
+                    global_store_quad<T>(out + ((long)(2 * oy + sdy) * (2 * p.Wo) + (2 * ox + sdx)) * p.ldo + sch0, v);
+                else
+                    global_store_quad<T>(out + ((long)oy * p.Wo + ox) * p.ldo + ch0, v);
+            }
         }
     }
 }
@@ -482,12 +572,13 @@ namespace {
 template <typename T, int MT>
 size_t head_lds(int kin, int c, bool adapt)
 {
-    return (size_t)Tile<MT>::M * ((kin + Traits<T>::kPad) + (adapt ? c + Traits<T>::kPad : 0)) * sizeof(T);
+    const int kx = kin > c ? kin : c;
+    return (size_t)Tile<MT>::M * ((kx + Traits<T>::kPad) + (adapt ? c + Traits<T>::kPad : 0)) * sizeof(T);
 }
-template <typename T, int MT>
+template <typename T, int MT, int NTW>
 size_t tail_lds(int c)
 {
-    return (size_t)Tile<MT>::M * ((c + Traits<T>::kPad) + (128 + Traits<T>::kPad)) * sizeof(T);
+    return TailLds<T, MT, TailCfg<MT, NTW>::NTV>::bytes(c);
 }
 
 template <typename K>
@@ -561,7 +652,11 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     tp.q = quant;
     tp.out = out;
     tp.ldo = ldo;
-    const size_t lds = tail_lds<T, MT>(C);
+    {
+        static const int abl = getenv("DCVC_ABLATE") ? atoi(getenv("DCVC_ABLATE")) : 0;
+        tp.ablate = abl;
+    }
+    const size_t lds = tail_lds<T, MT, NTW>(C);
     int rc = set_lds(dcb_tail_kernel<T, MT, NTW>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((dcb_tail_kernel<T, MT, NTW>), dim3(grid), dim3(NTHREADS), lds, st, tp);

@@ -8,6 +8,8 @@
 //     so every weight element is needed by exactly ONE wave: weights are pre-packed on the host
 //     into MFMA-fragment order and streamed global/L2 -> VGPR with one coalesced 16-byte (f16) or
 //     32-byte (f32) load per lane, never touching LDS and needing no barrier inside a K loop;
+//   * the weights are the MFMA "A" operand and the pixels the "B" operand, so a lane ends up with
+//     4 consecutive channels of one pixel (packed 8-byte epilogue accesses);
 //   * fp16 path: v_mfma_f32_16x16x32_f16 (fp32 accumulate);  fp32 "exact" path:
 //     v_mfma_f32_16x16x4_f32, whose result is bit-for-bit a k-ascending fmaf chain
 //     (MI355X_MICROARCH.md, Matrix cores), which oracle/nn_oracle.c reproduces on the CPU.
@@ -47,6 +49,13 @@ struct Traits<half_t> {
     }
     static __device__ __forceinline__ float to_f(half_t v) { return (float)v; }
     static __device__ __forceinline__ half_t from_f(float v) { return (half_t)v; }
+    // fp16 mode: hardware exp2 / rcp (about 1 ulp in fp32, far below the fp16 storage rounding);
+    // 5 VALU instructions instead of ~35 for the reproducible dcvc_wsiluf.
+    static __device__ __forceinline__ float wsilu(float x)
+    {
+        const float e = __builtin_amdgcn_exp2f(x * -5.770780163555854f);   // exp(-4x)
+        return x * __builtin_amdgcn_rcpf(1.0f + e);
+    }
 };
 
 template <>
@@ -66,42 +75,56 @@ struct Traits<float> {
     }
     static __device__ __forceinline__ float to_f(float v) { return v; }
     static __device__ __forceinline__ float from_f(float v) { return v; }
+    static __device__ __forceinline__ float wsilu(float x) { return dcvc_wsiluf(x); }   // bit-reproducible
 };
 
-// acc[m][i] += A[m-tile m][K] * W[n-tile tiles[i]][K]^T over `kgs` reduction groups.
-//   A      : LDS, row-major [16*MT][lda] in stored (perm) order, groups 0..kgs-1
+// acc[m][i] += W[n-tile tiles[i]][K] * X[pixel-tile m][K]^T over `kgs` reduction groups, with the
+// WEIGHTS as the MFMA "A" operand and the activation tile as the "B" operand, so the result tile is
+// channel-major in registers: lane l holds, for pixel m*16 + (l & 15), the four consecutive channels
+// tiles[i]*16 + 4*(l >> 4) + {0,1,2,3}  ->  8-byte (f16) packed LDS / global accesses in epilogues.
+//   X      : LDS, row-major [16*MT][ldx] in stored (perm) order, groups 0..kgs-1
 //   Wp     : packed weights, fragment (tile, group g) at Wp[(tile * kgs_total + g) * 64 + lane]
-//   kg0    : first group of W to use (A group g pairs with W group kg0 + g)
-template <typename T, int MT, int NT>
-__device__ __forceinline__ void gemm_acc(floatx4 (&acc)[MT][NT], const T* A, int lda, int kgs,
+//   kg0    : first group of W to use (X group g pairs with W group kg0 + g)
+// Weight fragments are prefetched PF groups ahead straight from L2 into registers (no LDS, no
+// barrier in the loop): one wave per SIMD has nobody else to hide the ~1 us L2 latency.
+template <typename T, int MT, int NT, int PF>
+__device__ __forceinline__ void gemm_acc(floatx4 (&acc)[MT][NT], const T* X, int ldx, int kgs,
                                          const typename Traits<T>::frag_t* __restrict__ Wp,
                                          int kgs_total, int kg0, const int (&tiles)[NT], int lane)
 {
     using frag_t = typename Traits<T>::frag_t;
     const int r = lane & 15, q = lane >> 4;
-    const T* a_base = A + r * lda + q * 8;
+    const T* x_base = X + r * ldx + q * 8;
     const frag_t* w_base[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) w_base[i] = Wp + ((size_t)tiles[i] * kgs_total + kg0) * 64 + lane;
 
-    frag_t bcur[NT];
+    frag_t w[PF][NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) bcur[i] = w_base[i][0];
-
-    for (int g = 0; g < kgs; ++g) {
-        frag_t bnext[NT];
-        const int gn = (g + 1 < kgs) ? g + 1 : g;
+    for (int s = 0; s < PF; ++s) {
+        const int g = s < kgs ? s : kgs - 1;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) bnext[i] = w_base[i][(size_t)gn * 64];
-        frag_t a[MT];
+        for (int i = 0; i < NT; ++i) w[s][i] = w_base[i][(size_t)g * 64];
+    }
+    for (int g0 = 0; g0 < kgs; g0 += PF) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const frag_t*>(a_base + m * 16 * lda + g * KG);
+        for (int s = 0; s < PF; ++s) {
+            const int g = g0 + s;
+            if (g < kgs) {
+                frag_t x[MT];
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+                for (int m = 0; m < MT; ++m) x[m] = *reinterpret_cast<const frag_t*>(x_base + m * 16 * ldx + g * KG);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][i] = Traits<T>::mma(a[m], bcur[i], acc[m][i]);
+                for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int i = 0; i < NT; ++i) bcur[i] = bnext[i];
+                    for (int m = 0; m < MT; ++m) acc[m][i] = Traits<T>::mma(w[s][i], x[m], acc[m][i]);
+                const int gn = g + PF;
+                if (gn < kgs) {
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) w[s][i] = w_base[i][(size_t)gn * 64];
+                }
+            }
+        }
     }
 }
 
@@ -115,9 +138,8 @@ __device__ __forceinline__ void zero_acc(floatx4 (&acc)[MT][NT])
 }
 
 // 16-byte vector load/store helpers ------------------------------------------------------------
-struct alignas(16) Vec16 {
-    uint32_t w[4];
-};
+typedef uint32_t Vec16 __attribute__((ext_vector_type(4)));   // a raw 16-byte vector (stays in VGPRs)
+#define VEC16_ZERO (Vec16{0u, 0u, 0u, 0u})
 
 template <typename T>
 __device__ __forceinline__ void unpack16(const Vec16& v, float (&f)[Traits<T>::kVec]);
@@ -125,14 +147,14 @@ __device__ __forceinline__ void unpack16(const Vec16& v, float (&f)[Traits<T>::k
 template <>
 __device__ __forceinline__ void unpack16<half_t>(const Vec16& v, float (&f)[8])
 {
-    const half_t* h = reinterpret_cast<const half_t*>(&v);
+    const half8 h = __builtin_bit_cast(half8, v);
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = (float)h[j];
 }
 template <>
 __device__ __forceinline__ void unpack16<float>(const Vec16& v, float (&f)[4])
 {
-    const float* h = reinterpret_cast<const float*>(&v);
+    const floatx4 h = __builtin_bit_cast(floatx4, v);
 #pragma unroll
     for (int j = 0; j < 4; ++j) f[j] = h[j];
 }
@@ -149,7 +171,95 @@ __device__ __forceinline__ void lds_store_vec<half_t>(half_t* buf, int ld, int r
 template <>
 __device__ __forceinline__ void lds_store_vec<float>(float* buf, int ld, int row, int c, const Vec16& v)
 {
-    const float* f = reinterpret_cast<const float*>(&v);
+    const floatx4 f = __builtin_bit_cast(floatx4, v);
 #pragma unroll
     for (int j = 0; j < 4; ++j) buf[row * ld + Traits<float>::perm(c + j)] = f[j];
+}
+
+// ---------------------------------------------------------------------------------------------
+// A lane's four consecutive channels [ch0, ch0+4) of pixel-row `row` <-> an LDS tile in stored order.
+template <typename T>
+__device__ __forceinline__ void lds_store_quad(T* buf, int ld, int row, int ch0, const floatx4& v);
+template <>
+__device__ __forceinline__ void lds_store_quad<half_t>(half_t* buf, int ld, int row, int ch0, const floatx4& v)
+{
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    *reinterpret_cast<half4*>(buf + row * ld + ch0) = h;
+}
+template <>
+__device__ __forceinline__ void lds_store_quad<float>(float* buf, int ld, int row, int ch0, const floatx4& v)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) buf[row * ld + Traits<float>::perm(ch0 + r)] = v[r];
+}
+
+template <typename T>
+__device__ __forceinline__ floatx4 lds_load_quad(const T* buf, int ld, int row, int ch0);
+template <>
+__device__ __forceinline__ floatx4 lds_load_quad<half_t>(const half_t* buf, int ld, int row, int ch0)
+{
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    const half4 h = *reinterpret_cast<const half4*>(buf + row * ld + ch0);
+    return floatx4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+template <>
+__device__ __forceinline__ floatx4 lds_load_quad<float>(const float* buf, int ld, int row, int ch0)
+{
+    floatx4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = buf[row * ld + Traits<float>::perm(ch0 + r)];
+    return v;
+}
+
+// one 16-byte vector [c, c+kVec) of row `row` of an LDS tile (stored order) <-> natural channel order
+template <typename T>
+__device__ __forceinline__ Vec16 lds_load_vec(const T* buf, int ld, int row, int c);
+template <>
+__device__ __forceinline__ Vec16 lds_load_vec<half_t>(const half_t* buf, int ld, int row, int c)
+{
+    return *reinterpret_cast<const Vec16*>(buf + row * ld + c);
+}
+template <>
+__device__ __forceinline__ Vec16 lds_load_vec<float>(const float* buf, int ld, int row, int c)
+{
+    floatx4 f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = buf[row * ld + Traits<float>::perm(c + j)];
+    return __builtin_bit_cast(Vec16, f);
+}
+
+template <typename T>
+__device__ __forceinline__ Vec16 pack16(const float (&f)[Traits<T>::kVec]);
+template <>
+__device__ __forceinline__ Vec16 pack16<half_t>(const float (&f)[8])
+{
+    half8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (half_t)f[j];
+    return __builtin_bit_cast(Vec16, h);
+}
+template <>
+__device__ __forceinline__ Vec16 pack16<float>(const float (&f)[4])
+{
+    floatx4 h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = f[j];
+    return __builtin_bit_cast(Vec16, h);
+}
+
+// direct global store of a quad (conv epilogues): 8 bytes (f16) / 16 bytes (f32)
+template <typename T>
+__device__ __forceinline__ void global_store_quad(T* p, const floatx4& v);
+template <>
+__device__ __forceinline__ void global_store_quad<half_t>(half_t* p, const floatx4& v)
+{
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    *reinterpret_cast<half4*>(p) = h;
+}
+template <>
+__device__ __forceinline__ void global_store_quad<float>(float* p, const floatx4& v)
+{
+    *reinterpret_cast<floatx4*>(p) = v;
 }

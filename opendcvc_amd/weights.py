@@ -13,20 +13,22 @@ from . import arch
 
 # Output heads of the prior networks: per output-channel chunk (count, bias mean, bias std), so
 # that the predicted Gaussian scales / means / quantisation steps land in the range a trained
-# model produces (scales mostly in [0.11, 1.5], |means| < 1, q_dec around 1).  With plain random
+# model produces (|means| < 1, q_dec around 1, and - like a trained model at a mid rate point -
+# most predicted scales below the force-zero threshold: about a quarter of the latent symbols
+# survive `scale > 0.12` and are entropy coded, the rest are skipped).  With plain random
 # heads almost every symbol would be escape-coded and the reference coder's one-byte-per-symbol
 # scratch buffer (rans.cpp:221) overflows.
 _HEAD_BIAS = {
     "dmc": {
-        "y_prior_fusion.conv.3": [(128, 1.0, 0.2), (128, 0.45, 0.35), (128, 0.0, 0.3)],
-        "y_spatial_prior.conv.2": [(128, 0.45, 0.35), (128, 0.0, 0.3)],
+        "y_prior_fusion.conv.3": [(128, 1.0, 0.2), (128, -0.05, 0.2), (128, 0.0, 0.1)],
+        "y_spatial_prior.conv.2": [(128, -0.05, 0.2), (128, 0.0, 0.1)],
     },
     "dmci": {
-        "y_prior_fusion.3": [(2, 0.0, 0.3), (256, 0.45, 0.35), (256, 0.0, 0.3)],
-        "y_spatial_prior.3": [(256, 0.45, 0.35), (256, 0.0, 0.3)],
+        "y_prior_fusion.3": [(2, 0.0, 0.3), (256, -0.05, 0.2), (256, 0.0, 0.1)],
+        "y_spatial_prior.3": [(256, -0.05, 0.2), (256, 0.0, 0.1)],
     },
 }
-_GAIN = {"encoder.down": 0.6, "enc.enc_2.6": 0.6, "decoder.conv2": 0.35, "feature_adaptor_p": 0.7}
+_GAIN = {"encoder.down": 0.2, "enc.enc_2.6": 0.2, "decoder.conv2": 0.35, "feature_adaptor_p": 0.7}
 
 
 def make_state_dict(model, seed=1234):
@@ -38,7 +40,7 @@ def make_state_dict(model, seed=1234):
         layer = name.rsplit(".", 1)[0]
         if layer in heads and kind in ("w", "b"):
             if kind == "w":
-                v = rng.standard_normal(shape) * (0.3 / np.sqrt(shape[1]))
+                v = rng.standard_normal(shape) * (0.15 / np.sqrt(shape[1]))
             else:
                 v = np.concatenate([rng.standard_normal(n) * sd_ + mu for n, mu, sd_ in heads[layer]])
         elif kind in ("w", "w_res"):
