@@ -30,6 +30,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from opendcvc_amd import _lib, weights  # noqa: E402
+from opendcvc_amd import dist as dist_utils  # noqa: E402
 from opendcvc_amd import nn as L  # noqa: E402
 from opendcvc_amd.models import DMC, DMCI  # noqa: E402
 from opendcvc_amd.pipeline import SequenceDecoder, SequenceEncoder, use_two_entropy_coders  # noqa: E402
@@ -47,21 +48,7 @@ def load_models(dtype, device, world, rank):
     sds = {}
     for name in ("dmci", "dmc"):
         sd = weights.make_state_dict(name, 1234) if rank == 0 else None
-        if world > 1:
-            import torch.distributed as dist
-            spec = weights.arch.spec_for(name).items
-            total = sum(int(np.prod(s)) for _, s, _ in spec)
-            blob = torch.empty(total, dtype=torch.float32, device=device)
-            if rank == 0:
-                blob.copy_(torch.from_numpy(np.concatenate([sd[k].reshape(-1) for k, _, _ in spec])))
-            dist.broadcast(blob, 0)            # one RCCL broadcast of the weight blob over xGMI
-            flat = blob.cpu().numpy()
-            sd, off = {}, 0
-            for k, s, _ in spec:
-                n = int(np.prod(s))
-                sd[k] = flat[off:off + n].reshape(s)
-                off += n
-        sds[name] = sd
+        sds[name] = dist_utils.broadcast_state_dict(name, sd, device, rank, world)   # one RCCL broadcast per model
 
     def make(cls, name):
         m = cls()
@@ -189,9 +176,7 @@ def main():
         return x_hat
 
     def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
+        dist_utils.barrier(world)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -201,12 +186,7 @@ def main():
     for _ in range(args.steps):
         step(True)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = dist_utils.max_over_ranks(time.perf_counter() - t0, device, world)
 
     if rank == 0:
         K, N = args.steps, world

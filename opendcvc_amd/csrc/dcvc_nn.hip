@@ -670,6 +670,7 @@ int dispatch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const floa
                  void* scratch, hipStream_t st, hipEvent_t* ev = nullptr)
 {
     switch (h->c_p / 64) {
+    case 1: return launch_dcb<T, MT, 1>(h, src, H, W, quant, out, ldo, scratch, st, ev);
     case 2: return launch_dcb<T, MT, 2>(h, src, H, W, quant, out, ldo, scratch, st, ev);
     case 3: return launch_dcb<T, MT, 3>(h, src, H, W, quant, out, ldo, scratch, st, ev);
     case 4: return launch_dcb<T, MT, 4>(h, src, H, W, quant, out, ldo, scratch, st, ev);

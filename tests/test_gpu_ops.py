@@ -1,0 +1,139 @@
+"""Operator-module seam (opendcvc_amd.ops == the reference's inference_extensions_cuda API) on the GPU
+against the reference's golden vectors (tests/golden/ops_small.npz) and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dcvc_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=2e-5, atol=2e-5)
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops_small.npz"))
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_process_with_mask_bit_exact(g):
+    from opendcvc_amd import ops
+    outs = ops.process_with_mask_cuda(cu(g["pwm.y"]), cu(g["pwm.scales"]), cu(g["pwm.means"]), cu(g["pwm.mask"]), 0.12)
+    for got, name in zip(outs, ("y_res", "y_q", "y_hat", "s_hat")):
+        assert np.array_equal(got.cpu().numpy(), g["pwm." + name]), name
+
+
+def test_build_index_enc_dec(g):
+    from opendcvc_amd import ops
+    sc, sym = cu(g["idx.scales"]), cu(g["idx.symbols"])
+    args = (0.11, 16.0, O.LOG_SCALE_MIN, O.LOG_STEP_RECIP, 0.12)
+    idx = torch.empty(sc.shape, dtype=torch.uint8, device="cuda")
+    cond = torch.empty(sc.shape, dtype=torch.bool, device="cuda")
+    ops.build_index_dec_cuda(idx, cond, sc, *args)
+    idx, cond = idx.cpu().numpy(), cond.cpu().numpy()
+    assert np.array_equal(cond, g["idx.dec_cond"])
+    s = np.clip(g["idx.scales"], np.float32(0.11), np.float32(16.0))
+    assert np.array_equal(idx, O.scale_to_index(s, 0.11, 16.0, O.LOG_SCALE_MIN, O.LOG_STEP_RECIP))   # == oracle
+    assert np.mean(idx != g["idx.dec_idx"]) <= 1e-3                                                    # ~ reference
+    out = torch.empty(sc.shape, dtype=torch.int16, device="cuda")
+    ops.build_index_enc_cuda(out, cond_t := torch.empty(sc.shape, dtype=torch.bool, device="cuda"), sym, sc, *args)
+    packed = out.cpu().numpy()[cond_t.cpu().numpy()]
+    assert np.mean(packed != g["idx.enc_packed"]) <= 1e-3
+
+
+def test_small_ops_bit_exact(g):
+    from opendcvc_amd import ops
+    z = cu(g["z.in"])
+    z8 = ops.round_and_to_int8_cuda(z)
+    assert np.array_equal(z.cpu().numpy(), g["z.hat"]) and np.array_equal(z8.cpu().numpy(), g["z.int8"])
+    y = cu(g["pwm.y"])
+    q = ops.clamp_reciprocal_with_quant_cuda(cu(g["crq.q"]), y, 0.5)
+    assert np.array_equal(q.cpu().numpy(), g["crq.q_out"]) and np.array_equal(y.cpu().numpy(), g["crq.y_out"])
+    assert np.array_equal(ops.replicate_pad_cuda(cu(g["pad.x"]), 3, 9).cpu().numpy(), g["pad.y"])
+    x = cu(g["ps8.x"])
+    out = torch.empty((1, 3, 16, 24), device="cuda")
+    ops.bias_pixel_shuffle_8_cuda(out, x, cu(g["ps8.b"]), 192, 6, 3, True)
+    assert np.array_equal(out.cpu().numpy(), g["ps8.y"])
+
+
+def test_mask_collapse_restore_and_scaling_ops():
+    from opendcvc_amd import ops
+    rng = np.random.default_rng(3)
+    C, H, W = 8, 5, 7
+    x = rng.standard_normal((1, C, H, W)).astype(np.float32)
+    m = (rng.random((1, C, H, W)) > 0.5).astype(np.float32)
+    out = torch.empty((1, C // 2, H, W), device="cuda")
+    ops.combine_for_reading_2x_cuda(out, cu(x), cu(m))
+    xm = x * m
+    assert np.array_equal(out.cpu().numpy(), xm[:, :C // 2] + xm[:, C // 2:])
+    for groups, fn in ((2, ops.restore_y_2x_cuda), (4, ops.restore_y_4x_cuda)):
+        y = rng.integers(-5, 6, (1, C // groups, H, W)).astype(np.float32)
+        out = torch.empty((1, C, H, W), device="cuda")
+        fn(out, cu(y), cu(x), cu(m))
+        assert np.array_equal(out.cpu().numpy(), (np.concatenate([y] * groups, 1) + x) * m)
+    a, b = cu(x), cu(m + 1)
+    qq = rng.uniform(0.5, 2, (1, C, H, W)).astype(np.float32)
+    ops.add_and_multiply_cuda(a, b, cu(qq))
+    assert np.array_equal(a.cpu().numpy(), (x + (m + 1)) * qq)
+    bias = rng.standard_normal(C).astype(np.float32)
+    qs = rng.uniform(0.5, 2, (1, C, 1, 1)).astype(np.float32)
+    t = cu(x)
+    ops.bias_quant_cuda(t, cu(bias), cu(qs))
+    assert np.array_equal(t.cpu().numpy(), (x + bias[None, :, None, None]) * qs)
+
+
+def test_bias_wsilu_depthwise_matches_oracle():
+    from opendcvc_amd import ops
+    rng = np.random.default_rng(4)
+    C, H, W = 16, 6, 9
+    x = rng.standard_normal((1, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((C, 1, 3, 3)) / 3).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    got = ops.bias_wsilu_depthwise_conv2d_cuda(cu(x), cu(w), cu(b)).cpu().numpy()
+    act = O.wsilu(O.nchw_to_hwc(x) + b)
+    ref = np.empty((H, W, C), np.float32)
+    import ctypes
+    O.lib().orc_dw3x3(O._ptr(act), H, W, C, O._ptr(w), None, O._ptr(ref))
+    assert np.array_equal(got, O.hwc_to_nchw(ref))
+
+
+def _sub(g, prefix):
+    pre = prefix + ".w."
+    return {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
+
+
+@pytest.mark.parametrize("name,short", [("dcb_plain", False), ("dcb_adapt", False), ("dcb_short", True),
+                                        ("dcb_quant", False), ("dcb_force", False), ("dcb_adapt_short_q", True)])
+def test_depth_conv_proxy_vs_reference(g, name, short):
+    from opendcvc_amd import ops
+    w = {k: cu(v) for k, v in _sub(g, name).items()}
+    p = ops.DepthConvProxy()
+    base = [w["dc.0.weight"], w["dc.0.bias"], w["dc.2.weight"], w["dc.2.bias"], w["dc.3.weight"], w["dc.3.bias"],
+            w["ffn.0.weight"], w["ffn.0.bias"], w["ffn.2.weight"], w["ffn.2.bias"]]
+    if "adaptor.weight" in w:
+        p.set_param_with_adaptor(*base, w["adaptor.weight"], w["adaptor.bias"], short)
+    else:
+        p.set_param(*base, short)
+    x = cu(g[name + ".x"])
+    if (name + ".q") in g.files:
+        y = p.forward_with_quant_step(x, cu(g[name + ".q"]))
+    else:
+        y = p.forward(x)
+    np.testing.assert_allclose(y.cpu().numpy(), g[name + ".y"], **TOL)
+    cat = p.forward_with_cat(x, x, True) if (name + ".q") not in g.files else None
+    if cat is not None:
+        assert cat.shape[1] == x.shape[1] + g[name + ".y"].shape[1]
+
+
+@pytest.mark.parametrize("name,pad", [("subpel1", 0), ("subpel3", 1)])
+def test_subpel_proxy_vs_reference(g, name, pad):
+    from opendcvc_amd import ops
+    w = _sub(g, name)
+    p = ops.SubpelConv2xProxy()
+    p.set_param(cu(w["conv.0.weight"]), cu(w["conv.0.bias"]), pad)
+    np.testing.assert_allclose(p.forward(cu(g[name + ".x"])).cpu().numpy(), g[name + ".y"], **TOL)
