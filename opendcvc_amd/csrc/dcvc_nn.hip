@@ -2,6 +2,8 @@
 // (2 kernels instead of the reference's 8 launches, impl.cpp:53-121) and implicit-GEMM dense
 // convolutions (1x1, 3x3 s1/s2, 2x2 s2) with fused bias / quant / PixelShuffle(2) / WSiLU epilogues.
 // Decomposition and operand layouts: gemm_core.hpp.  C ABI: include/dcvc_amd.h.
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <memory>
@@ -176,7 +178,17 @@ struct TailParams {
     void* out;
     long ldo;
     int ablate;          // debug: bit0 skip dw, bit1 skip GEMM2, bit2 skip FFN GEMM3, bit3 skip FFN GEMM4
+    unsigned long long* stamps;   // diagnostic build only (DCVC_STAMPS): 8 cycle counters per workgroup
 };
+
+#define STAMP(var)                                                   \
+    do {                                                             \
+        if (p.stamps) {                                              \
+            __builtin_amdgcn_sched_barrier(0);                       \
+            var = __builtin_amdgcn_s_memtime();                      \
+            __builtin_amdgcn_sched_barrier(0);                       \
+        }                                                            \
+    } while (0)
 
 constexpr int DW_SLAB = 64;   // channels per depthwise slab staged in LDS (with its 1-pixel halo)
 
@@ -207,6 +219,7 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
     using LD = TailLds<T, MT, NTV>;
     constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH, V = TR::kVec;
     constexpr int PF = TailCfg<MT, NTW>::two_per_cu ? 2 : Pf<T>::value;
+    constexpr int PF3 = (sizeof(T) == 2 && NTV == 1) ? 4 : PF;   // GEMM3 has few MFMAs per k-group: look further ahead
     constexpr int VC = NWAVE * NTV * 16;          // v columns per chunk
     static_assert(VC == LD::VC, "chunk width");
     extern __shared__ __attribute__((aligned(32))) char smem[];
@@ -222,6 +235,14 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
     const T* a = reinterpret_cast<const T*>(p.a);
     const T* ident = reinterpret_cast<const T*>(p.ident);
     const int GC = C / V;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tg3 = 0, tep = 0, tg4 = 0, tt = 0, tt2 = 0;
+    STAMP(ts0);
+    const int pl = lane & 15, cq = (lane >> 4) * 4;
+    int tiles[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) tiles[i] = wave + NWAVE * i;
+    WPre<T, NTW, PF> pre2;   // W2's first groups are requested now and land during the depthwise stage
+    gemm_prefetch<T, NTW, PF>(pre2, C / KG, reinterpret_cast<const frag_t*>(p.w2), C / KG, 0, tiles, lane);
 
     {   // depthwise 3x3 (zero padding), taps in (ky,kx) order, + bias.  The activation tile and its
         // 1-pixel halo go through LDS one 64-channel slab at a time (each input element is fetched
@@ -255,11 +276,21 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
                     *reinterpret_cast<Vec16*>(bufV + hp * lds_s + cs) = pre[k];   // natural order inside the slab
                 }
             }
+            // a thread always works on the same channel group of a slab (NTHREADS % GS == 0): its 9 tap
+            // weights and the bias are fetched once per slab, before the barrier
+            const int cs = (tid % GS) * V, c = slab * DW_SLAB + cs;
+            Vec16 wtap[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wtap[t] = *reinterpret_cast<const Vec16*>(wd + t * C + c);
+            float bdv[V];
+#pragma unroll
+            for (int j = 0; j < V; j += 4) {
+                const floatx4 b4 = load_f4(p.bd + c + j);
+                bdv[j] = b4[0]; bdv[j + 1] = b4[1]; bdv[j + 2] = b4[2]; bdv[j + 3] = b4[3];
+            }
             __syncthreads();
             if (slab + 1 < nslab) fetch(slab + 1);
-            for (int it = tid; it < M * GS; it += NTHREADS) {
-                const int m = it / GS, cs = (it - m * GS) * V;
-                const int c = slab * DW_SLAB + cs;
+            for (int m = tid / GS; m < M; m += NTHREADS / GS) {
                 const int my = m / TW, mx = m % TW;
                 float s[V];
 #pragma unroll
@@ -270,28 +301,48 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
                     for (int kx = 0; kx < 3; ++kx) {
                         float av[V], wv[V];
                         unpack16<T>(*reinterpret_cast<const Vec16*>(bufV + ((my + ky) * HW_ + mx + kx) * lds_s + cs), av);
-                        unpack16<T>(*reinterpret_cast<const Vec16*>(wd + (ky * 3 + kx) * C + c), wv);
+                        unpack16<T>(wtap[ky * 3 + kx], wv);
 #pragma unroll
                         for (int j = 0; j < V; ++j) s[j] = DCVC_FMAF(av[j], wv[j], s[j]);
                     }
 #pragma unroll
-                for (int j = 0; j < V; ++j) s[j] = s[j] + p.bd[c + j];
+                for (int j = 0; j < V; ++j) s[j] = s[j] + bdv[j];
                 lds_store_vec<T>(bufX, ldx, m, c, pack16<T>(s));
             }
             __syncthreads();
         }
     }
 
-    int tiles[NTW];
+    STAMP(ts1);
+
+    // identity rows for the o = ... + x' pass: requested before GEMM2 so they arrive underneath it
+    constexpr int NID = (M * (64 * NTW / V) + NTHREADS - 1) / NTHREADS;
+    Vec16 idv[NID];
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) tiles[i] = wave + NWAVE * i;
-    const int pl = lane & 15, cq = (lane >> 4) * 4;
+    for (int k = 0; k < NID; ++k) {
+        const int it = tid + k * NTHREADS;
+        const int m = it / GC, c = (it - m * GC) * V;
+        const int y = ty0 + m / TW, x = tx0 + m % TW;
+        idv[k] = VEC16_ZERO;
+        if (it < M * GC && y < p.H && x < p.W)
+            idv[k] = *reinterpret_cast<const Vec16*>(ident + ((long)y * p.W + x) * p.ldi + c);
+    }
 
     floatx4 acc[MT][NTW];
     zero_acc(acc);
     if (!(p.ablate & 2))
-        gemm_acc<T, MT, NTW, PF>(acc, bufX, ldx, C / KG, reinterpret_cast<const frag_t*>(p.w2), C / KG, 0, tiles, lane);
+        gemm_run<T, MT, NTW, PF>(acc, bufX, ldx, C / KG, pre2, reinterpret_cast<const frag_t*>(p.w2), C / KG, 0, tiles, lane);
+    const int vtiles = 2 * C / 16;
+    int ut[2 * NTV];
+#pragma unroll
+    for (int j = 0; j < NTV; ++j) {
+        ut[j] = wave * NTV + j;
+        ut[j + NTV] = ut[j] + vtiles;
+    }
+    WPre<T, 2 * NTV, PF3> pre3;
+    gemm_prefetch<T, 2 * NTV, PF3>(pre3, C / KG, reinterpret_cast<const frag_t*>(p.w3), C / KG, 0, ut, lane);
     __syncthreads();   // every wave has finished reading d
+    STAMP(ts2);
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         const int ch0 = tiles[i] * 16 + cq;
@@ -300,14 +351,15 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
         for (int m = 0; m < MT; ++m) lds_store_quad<T>(bufX, ldx, m * 16 + pl, ch0, acc[m][i] + bias);
     }
     __syncthreads();
-    // o = (W2 d + b2) + x'   (identity added with coalesced 16-byte global loads)
-    for (int it = tid; it < M * GC; it += NTHREADS) {
-        const int m = it / GC, c = (it - m * GC) * V;
-        const int y = ty0 + m / TW, x = tx0 + m % TW;
-        if (y < p.H && x < p.W) {
+    // o = (W2 d + b2) + x'   (identity rows were loaded with coalesced 16-byte loads above)
+#pragma unroll
+    for (int k = 0; k < NID; ++k) {
+        const int it = tid + k * NTHREADS;
+        if (it < M * GC) {
+            const int m = it / GC, c = (it - m * GC) * V;
             float o[V], id[V];
             unpack16<T>(lds_load_vec<T>(bufX, ldx, m, c), o);
-            unpack16<T>(*reinterpret_cast<const Vec16*>(ident + ((long)y * p.W + x) * p.ldi + c), id);
+            unpack16<T>(idv[k], id);
 #pragma unroll
             for (int j = 0; j < V; ++j) o[j] = o[j] + id[j];
             lds_store_vec<T>(bufX, ldx, m, c, pack16<T>(o));
@@ -315,29 +367,32 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
     }
     __syncthreads();
 
+    STAMP(ts3);
     // FFN: C -> 4C -> chunk-add -> 2C -> C, the 4C-wide intermediate never leaves the CU
     zero_acc(acc);
-    const int vtiles = 2 * C / 16;
     const int chunks = vtiles / (NWAVE * NTV);
     for (int ch = 0; ch < chunks; ++ch) {
         floatx4 u[MT][2 * NTV];
         zero_acc(u);
-        int ut[2 * NTV];
+        floatx4 blo[NTV], bhi[NTV];
 #pragma unroll
-        for (int j = 0; j < NTV; ++j) {
-            ut[j] = ch * NWAVE * NTV + wave * NTV + j;
-            ut[j + NTV] = ut[j] + vtiles;
+        for (int j = 0; j < NTV; ++j) {   // biases requested before the GEMM that hides their latency
+            blo[j] = load_f4(p.b3 + ut[j] * 16 + cq);
+            bhi[j] = load_f4(p.b3 + ut[j] * 16 + cq + 2 * C);
         }
+        STAMP(tt);
         if (!(p.ablate & 4))
-            gemm_acc<T, MT, 2 * NTV, PF>(u, bufX, ldx, C / KG, reinterpret_cast<const frag_t*>(p.w3), C / KG, 0, ut, lane);
+            gemm_run<T, MT, 2 * NTV, PF3>(u, bufX, ldx, C / KG, pre3, reinterpret_cast<const frag_t*>(p.w3), C / KG, 0, ut, lane);
+        STAMP(tt2);
+        tg3 += tt2 - tt;
+        WPre<T, NTW, PF> pre4;   // W4's groups for this chunk arrive underneath the activation epilogue
+        gemm_prefetch<T, NTW, PF>(pre4, VC / KG, reinterpret_cast<const frag_t*>(p.w4), 2 * C / KG, ch * (VC / KG), tiles, lane);
 #pragma unroll
         for (int j = 0; j < NTV; ++j) {
-            const int vch0 = ut[j] * 16 + cq;
-            const floatx4 blo = load_f4(p.b3 + vch0), bhi = load_f4(p.b3 + vch0 + 2 * C);
             const int lch0 = (wave * NTV + j) * 16 + cq;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const floatx4 lo = u[m][j] + blo, hi = u[m][j + NTV] + bhi;
+                const floatx4 lo = u[m][j] + blo[j], hi = u[m][j + NTV] + bhi[j];
                 floatx4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = TR::wsilu(lo[r]) + TR::wsilu(hi[r]);
@@ -345,11 +400,21 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
             }
         }
         __syncthreads();
+        STAMP(tt);
+        tep += tt - tt2;
         if (!(p.ablate & 8))
-            gemm_acc<T, MT, NTW, PF>(acc, bufV, ldv, VC / KG, reinterpret_cast<const frag_t*>(p.w4), 2 * C / KG,
+            gemm_run<T, MT, NTW, PF>(acc, bufV, ldv, VC / KG, pre4, reinterpret_cast<const frag_t*>(p.w4), 2 * C / KG,
                                      ch * (VC / KG), tiles, lane);
+        if (ch + 1 < chunks) {   // next chunk's first W3 groups, requested before the barrier
+#pragma unroll
+            for (int j = 0; j < 2 * NTV; ++j) ut[j] += NWAVE * NTV;
+            gemm_prefetch<T, 2 * NTV, PF3>(pre3, C / KG, reinterpret_cast<const frag_t*>(p.w3), C / KG, 0, ut, lane);
+        }
         __syncthreads();
+        STAMP(tt2);
+        tg4 += tt2 - tt;
     }
+    STAMP(ts4);
 
     // r = (W4 v + b4) + o, accumulated in place in LDS (each element is owned by one lane)
 #pragma unroll
@@ -382,6 +447,22 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
                 for (int j = 0; j < V; ++j) r[j] = r[j] * ((c + j) < p.c_log ? p.q[c + j] : 1.0f);
             }
             *reinterpret_cast<Vec16*>(out + pix * p.ldo + c) = pack16<T>(r);
+        }
+    }
+    if (p.stamps) {
+        unsigned long long te = 0;
+        __syncthreads();
+        STAMP(te);
+        if (tid == 0) {
+            unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+            o[0] = ts1 - ts0;   // depthwise
+            o[1] = ts2 - ts1;   // GEMM2 k-loop
+            o[2] = ts3 - ts2;   // o = +b2 +x'
+            o[3] = tg3;         // FFN GEMM3
+            o[4] = tep;         // FFN wsilu/chunk-add + LDS store + barrier
+            o[5] = tg4;         // FFN GEMM4
+            o[6] = te - ts4;    // final epilogue + store
+            o[7] = te - ts0;    // total
         }
     }
 }
@@ -656,12 +737,36 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         static const int abl = getenv("DCVC_ABLATE") ? atoi(getenv("DCVC_ABLATE")) : 0;
         tp.ablate = abl;
     }
+    static const bool want_stamps = getenv("DCVC_STAMPS") != nullptr;
+    unsigned long long* d_stamps = nullptr;
+    if (want_stamps) {
+        DCVC_HIP(hipMalloc(&d_stamps, (size_t)grid * 8 * sizeof(unsigned long long)));
+        tp.stamps = d_stamps;
+    }
     const size_t lds = tail_lds<T, MT, NTW>(C);
     int rc = set_lds(dcb_tail_kernel<T, MT, NTW>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((dcb_tail_kernel<T, MT, NTW>), dim3(grid), dim3(NTHREADS), lds, st, tp);
     DCVC_LAUNCH_CHECK();
     if (ev) DCVC_HIP(hipEventRecord(ev[2], st));
+    if (want_stamps) {   // diagnostic only: median cycles per phase over the workgroups
+        DCVC_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> hs((size_t)grid * 8);
+        DCVC_HIP(hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(d_stamps);
+        static int printed = 0;
+        if (printed++ % 16 == 15) {
+            const char* names[8] = {"dw", "gemm2", "o_pass", "gemm3", "ffn_epi", "gemm4", "final", "total"};
+            fprintf(stderr, "[stamps C=%d MT=%d grid=%d]", C, MT, grid);
+            for (int k = 0; k < 8; ++k) {
+                std::vector<unsigned long long> v(grid);
+                for (int b = 0; b < grid; ++b) v[b] = hs[(size_t)b * 8 + k];
+                std::sort(v.begin(), v.end());
+                fprintf(stderr, " %s=%llu", names[k], v[grid / 2]);
+            }
+            fprintf(stderr, "\n");
+        }
+    }
     return 0;
 }
 
@@ -669,6 +774,14 @@ template <typename T, int MT>
 int dispatch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float* quant, void* out, int64_t ldo,
                  void* scratch, hipStream_t st, hipEvent_t* ev = nullptr)
 {
+    if constexpr (MT >= 8) {   // 128-pixel tiles: only the widths whose accumulators fit (<= 320 channels)
+        switch (h->c_p / 64) {
+        case 2: return launch_dcb<T, MT, 2>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+        case 4: return launch_dcb<T, MT, 4>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+        case 5: return launch_dcb<T, MT, 5>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+        default: dcvc::set_error("DepthConvBlock width %d has no 128-pixel variant", h->c_p); return dcvc::E_ARG;
+        }
+    }
     switch (h->c_p / 64) {
     case 1: return launch_dcb<T, MT, 1>(h, src, H, W, quant, out, ldo, scratch, st, ev);
     case 2: return launch_dcb<T, MT, 2>(h, src, H, W, quant, out, ldo, scratch, st, ev);
@@ -701,6 +814,44 @@ int dispatch_conv(const dcvc_conv* h, const ConvParams& cp, hipStream_t st)
     if (nt <= 8) return launch_conv<T, MT, 2>(h, cp, st);
     if (nt <= 12) return launch_conv<T, MT, 3>(h, cp, st);
     return launch_conv<T, MT, 4>(h, cp, st);
+}
+
+
+// Pixel-tile height selection (f16): 16*MT pixels per workgroup.  Small feature maps take smaller
+// tiles so that the grid still covers the 256 CUs; DCVC_MT overrides for experiments.
+static int pick_mt_f16(int H, int W, int c_p)
+{
+    static const int forced = getenv("DCVC_MT") ? atoi(getenv("DCVC_MT")) : 0;
+    if (forced == 2 || forced == 4 || (forced == 8 && c_p <= 320)) return forced;
+    const long P = (long)H * W;
+    (void)c_p;
+    return P >= 12000 ? 4 : 2;
+}
+
+template <int MT>
+int dispatch_dcb_f16(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float* quant, void* out, int64_t ldo,
+                     void* scratch, hipStream_t st, hipEvent_t* ev)
+{
+    return dispatch_dcb<half_t, MT>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+}
+
+static int run_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float* quant, void* out, int64_t ldo,
+                   void* scratch, hipStream_t st, hipEvent_t* ev)
+{
+    if (h->dtype != DCVC_F16) return dispatch_dcb<float, 2>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+    switch (pick_mt_f16(H, W, h->c_p)) {
+    case 2: return dispatch_dcb_f16<2>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+    case 8: return dispatch_dcb_f16<8>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+    default: return dispatch_dcb_f16<4>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+    }
+}
+
+static int run_conv(const dcvc_conv* h, const ConvParams& cp, hipStream_t st)
+{
+    if (h->dtype != DCVC_F16) return dispatch_conv<float, 2>(h, cp, st);
+    const long P = (long)cp.Ho * cp.Wo;
+    if (P >= 12000) return dispatch_conv<half_t, 4>(h, cp, st);
+    return dispatch_conv<half_t, 2>(h, cp, st);
 }
 
 }  // namespace
@@ -770,8 +921,7 @@ int dcvc_dcb_forward(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, con
                  "dcvc_dcb_forward: inputs must be 16-byte aligned");
     SrcPair src{x0, (long)ld0, c0, x1, (long)ld1, c1};
     hipStream_t st = (hipStream_t)stream;
-    if (h->dtype == DCVC_F16) return dispatch_dcb<half_t, 4>(h, src, H, W, quant, out, ldo, scratch, st);
-    return dispatch_dcb<float, 2>(h, src, H, W, quant, out, ldo, scratch, st);
+    return run_dcb(h, src, H, W, quant, out, ldo, scratch, st, nullptr);
 }
 
 int dcvc_dcb_profile(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, int H, int W, void* out, int64_t ldo,
@@ -785,8 +935,7 @@ int dcvc_dcb_profile(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, int
     for (auto& e : ev) DCVC_HIP(hipEventCreate(&e));
     int rc = 0;
     for (int i = 0; i < iters && rc == 0; ++i)
-        rc = h->dtype == DCVC_F16 ? dispatch_dcb<half_t, 4>(h, src, H, W, nullptr, out, ldo, scratch, st, &ev[3 * i])
-                                  : dispatch_dcb<float, 2>(h, src, H, W, nullptr, out, ldo, scratch, st, &ev[3 * i]);
+        rc = run_dcb(h, src, H, W, nullptr, out, ldo, scratch, st, &ev[3 * i]);
     if (rc == 0) {
         DCVC_HIP(hipStreamSynchronize(st));
         double th = 0, tt = 0;
@@ -882,8 +1031,7 @@ int dcvc_conv_forward(const dcvc_conv* h, const void* x0, int64_t ld0, int c0, c
     cp.ldo = ldo;
     DCVC_REQUIRE(ldo >= (h->epi == DCVC_EPI_SHUFFLE2 ? h->cs_p : h->n_p), "dcvc_conv_forward: output row stride too small");
     hipStream_t st = (hipStream_t)stream;
-    if (h->dtype == DCVC_F16) return dispatch_conv<half_t, 4>(h, cp, st);
-    return dispatch_conv<float, 2>(h, cp, st);
+    return run_conv(h, cp, st);
 }
 
 }  // extern "C"

@@ -85,12 +85,32 @@ struct Traits<float> {
 //   X      : LDS, row-major [16*MT][ldx] in stored (perm) order, groups 0..kgs-1
 //   Wp     : packed weights, fragment (tile, group g) at Wp[(tile * kgs_total + g) * 64 + lane]
 //   kg0    : first group of W to use (X group g pairs with W group kg0 + g)
-// Weight fragments are prefetched PF groups ahead straight from L2 into registers (no LDS, no
-// barrier in the loop): one wave per SIMD has nobody else to hide the ~1 us L2 latency.
+// Weight fragments go straight from L2 into registers (no LDS, no barrier in the loop), PF groups
+// ahead.  The first PF groups can be requested early with gemm_prefetch() - before the barrier /
+// epilogue that precedes the GEMM - so the ~1 us L2 latency of a cold start is not exposed
+// (one wave per SIMD per workgroup has nobody else to hide it).
+template <typename T, int NT, int PF>
+struct WPre {
+    typename Traits<T>::frag_t w[PF][NT];
+};
+
+template <typename T, int NT, int PF>
+__device__ __forceinline__ void gemm_prefetch(WPre<T, NT, PF>& pre, int kgs,
+                                              const typename Traits<T>::frag_t* __restrict__ Wp, int kgs_total,
+                                              int kg0, const int (&tiles)[NT], int lane)
+{
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+        const int g = s < kgs ? s : kgs - 1;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) pre.w[s][i] = Wp[((size_t)tiles[i] * kgs_total + kg0 + g) * 64 + lane];
+    }
+}
+
 template <typename T, int MT, int NT, int PF>
-__device__ __forceinline__ void gemm_acc(floatx4 (&acc)[MT][NT], const T* X, int ldx, int kgs,
-                                         const typename Traits<T>::frag_t* __restrict__ Wp,
-                                         int kgs_total, int kg0, const int (&tiles)[NT], int lane)
+__device__ __forceinline__ void gemm_run(floatx4 (&acc)[MT][NT], const T* X, int ldx, int kgs, WPre<T, NT, PF>& pre,
+                                         const typename Traits<T>::frag_t* __restrict__ Wp, int kgs_total, int kg0,
+                                         const int (&tiles)[NT], int lane)
 {
     using frag_t = typename Traits<T>::frag_t;
     const int r = lane & 15, q = lane >> 4;
@@ -98,14 +118,6 @@ __device__ __forceinline__ void gemm_acc(floatx4 (&acc)[MT][NT], const T* X, int
     const frag_t* w_base[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) w_base[i] = Wp + ((size_t)tiles[i] * kgs_total + kg0) * 64 + lane;
-
-    frag_t w[PF][NT];
-#pragma unroll
-    for (int s = 0; s < PF; ++s) {
-        const int g = s < kgs ? s : kgs - 1;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) w[s][i] = w_base[i][(size_t)g * 64];
-    }
     for (int g0 = 0; g0 < kgs; g0 += PF) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
@@ -117,15 +129,25 @@ __device__ __forceinline__ void gemm_acc(floatx4 (&acc)[MT][NT], const T* X, int
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m][i] = Traits<T>::mma(w[s][i], x[m], acc[m][i]);
+                    for (int m = 0; m < MT; ++m) acc[m][i] = Traits<T>::mma(pre.w[s][i], x[m], acc[m][i]);
                 const int gn = g + PF;
                 if (gn < kgs) {
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) w[s][i] = w_base[i][(size_t)gn * 64];
+                    for (int i = 0; i < NT; ++i) pre.w[s][i] = w_base[i][(size_t)gn * 64];
                 }
             }
         }
     }
+}
+
+template <typename T, int MT, int NT, int PF>
+__device__ __forceinline__ void gemm_acc(floatx4 (&acc)[MT][NT], const T* X, int ldx, int kgs,
+                                         const typename Traits<T>::frag_t* __restrict__ Wp,
+                                         int kgs_total, int kg0, const int (&tiles)[NT], int lane)
+{
+    WPre<T, NT, PF> pre;
+    gemm_prefetch<T, NT, PF>(pre, kgs, Wp, kgs_total, kg0, tiles, lane);
+    gemm_run<T, MT, NT, PF>(acc, X, ldx, kgs, pre, Wp, kgs_total, kg0, tiles, lane);
 }
 
 template <int MT, int NT>
