@@ -199,6 +199,47 @@ def gen_ops(L, O):
     np.savez_compressed(os.path.join(HERE, "ops_small.npz"), **out)
 
 
+def gen_container(S):
+    """Container KATs from the reference's stream_helper (stream_helper.py:68-217)."""
+    import io
+    out = {"varint": [], "sps": [], "ip": []}
+    for v in (0, 1, 127, 128, 129, 255, 256, 16383, 16384, 65535, 70000, (1 << 24) + 5, (1 << 30) - 1):
+        f = io.BytesIO()
+        n = S.write_uint_adaptive(f, v)
+        out["varint"].append({"value": v, "hex": f.getvalue().hex(), "n": n})
+    for sps in ({"sps_id": 0, "height": 1080, "width": 1920, "ec_part": 1, "use_ada_i": 0},
+                {"sps_id": 3, "height": 64, "width": 64, "ec_part": 0, "use_ada_i": 1},
+                {"sps_id": 15, "height": 2160, "width": 3840, "ec_part": 1, "use_ada_i": 1},
+                {"sps_id": 1, "height": 20000, "width": 100, "ec_part": 0, "use_ada_i": 0}):
+        f = io.BytesIO()
+        n = S.write_sps(f, sps)
+        out["sps"].append({"sps": sps, "hex": f.getvalue().hex(), "n": n})
+    rng = np.random.default_rng(5)
+    for is_i, sps_id, qp, ln in ((True, 0, 0, 0), (False, 2, 63, 5), (False, 15, 255, 130), (True, 1, 32, 20000)):
+        payload = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+        f = io.BytesIO()
+        n = S.write_ip(f, is_i, sps_id, qp, payload)
+        out["ip"].append({"is_i": is_i, "sps_id": sps_id, "qp": qp, "payload_sha256": sha(payload), "payload_len": ln,
+                          "hex_head": f.getvalue()[:8].hex(), "sha256": sha(f.getvalue()), "n": n})
+    # a whole multi-frame stream with SPS dedup, as test_video.py:216-224 writes it
+    f = io.BytesIO()
+    helper = S.SPSHelper()
+    frames = [(True, 32, 0, 300), (False, 40, 1, 90), (False, 32, 0, 70), (False, 36, 0, 16500), (False, 32, 1, 10)]
+    spec = []
+    for is_i, qp, ada, ln in frames:
+        payload = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+        sps = {"sps_id": -1, "height": 1080, "width": 1920, "ec_part": 1, "use_ada_i": ada}
+        sps_id, new = helper.get_sps_id(sps)
+        sps["sps_id"] = sps_id
+        if new:
+            S.write_sps(f, sps)
+        S.write_ip(f, is_i, sps_id, qp, payload)
+        spec.append({"is_i": is_i, "qp": qp, "use_ada_i": ada, "payload_hex": payload.hex() if ln < 400 else None,
+                     "payload_sha256": sha(payload), "payload_len": ln})
+    out["stream"] = {"frames": spec, "sha256": sha(f.getvalue()), "n": len(f.getvalue()), "seed": 5}
+    json.dump(out, open(os.path.join(HERE, "container_kat.json"), "w"), indent=1)
+
+
 def run_sequence(i_net, p_net, h, w, n_frames, qp, two, reset_interval, keep_tensors):
     """Encode then decode a short sequence the way test_video.py:164-214,258-285 drives the models."""
     rec = dict(h=h, w=w, qp=qp, two=int(two), reset_interval=reset_interval, seed=SEED, thres=THRES,
@@ -260,6 +301,7 @@ def main():
     torch.set_grad_enabled(False)
     torch.manual_seed(0)
     gen_rans(R)
+    gen_container(S)
     gen_ops(L, O)
     i_net, p_net = load_models(DMC, DMCI)
     gen_tables(i_net, p_net)
