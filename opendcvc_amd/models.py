@@ -195,19 +195,30 @@ class CompressionModel(tnn.Module):
         check(_lib.lib().dcvc_prior_finish(L.dtype_code(yhat.dtype), q_mode, L._p(yhat), ld, L._p(qsrc), qsrc.stride(1),
                                            H, W, C, self._stream()), "prior_finish")
 
-    def _decode_step(self, groups, step, scales, means, yhat, H, W, C, key):
-        """one checkerboard step of the decoder: indexes -> host rANS -> symbols -> y_hat"""
+    def _decode_step_begin(self, groups, step, scales, H, W, C, key):
+        """first half of a checkerboard decode step: cdf indexes on the GPU -> pinned host buffer.
+        Returns a ticket; GPU work queued after this call overlaps with the host entropy decoding."""
         n = (C // groups) * H * W
-        dev = yhat.device
-        idx = torch.empty(n, dtype=torch.uint8, device=dev)
+        idx = torch.empty(n, dtype=torch.uint8, device=scales.device)
         self._prior_dec_index(groups, step, scales, H, W, C, idx)
         hb = self._d2h(key + "_idx", idx)
-        check(_lib.lib().dcvc_stream_sync(self._stream()), "stream sync")
+        ev = torch.cuda.Event()
+        ev.record()
+        return (n, hb, ev, key, idx)
+
+    def _decode_step_end(self, ticket, groups, step, means, yhat, H, W, C):
+        """second half: wait for the indexes only, rANS-decode on the host, upload, restore y_hat."""
+        n, hb, ev, key, _ = ticket
+        ev.synchronize()
         sb = self.entropy_coder.pinned(key + "_sym", n)
         self.entropy_coder.decode_and_get_y(hb.view(np.uint8, n), self._g_group, sb.view(np.int8, n))
-        sym = torch.empty(n, dtype=torch.int8, device=dev)
+        sym = torch.empty(n, dtype=torch.int8, device=yhat.device)
         check(_lib.lib().dcvc_memcpy_h2d(L._p(sym), ctypes.c_void_p(sb.ptr), n, self._stream()), "h2d")
         self._prior_dec_restore(groups, step, sym, means, yhat, H, W, C)
+
+    def _decode_step(self, groups, step, scales, means, yhat, H, W, C, key):
+        self._decode_step_end(self._decode_step_begin(groups, step, scales, H, W, C, key), groups, step, means, yhat,
+                              H, W, C)
 
 
 # =============================================================================== DMC (P frames)
@@ -403,8 +414,9 @@ class DMC(CompressionModel):
         z_hat = self._z_to_device(zb.view(np.int8, self.z_channel * zh * zw), zh, zw, dtype, device)
         params = self._prior_params(z_hat, ctx_t, yh, yw)
         y_hat = torch.empty((yh, yw, C), dtype=dtype, device=device)
-        ctx = self._extractor_part2(x1)
-        self._decode_step(2, 0, params[:, :, C:2 * C], params[:, :, 2 * C:], y_hat, yh, yw, C, "p0")
+        ticket = self._decode_step_begin(2, 0, params[:, :, C:2 * C], yh, yw, C, "p0")
+        ctx = self._extractor_part2(x1)          # runs on the GPU while the host decodes step 0
+        self._decode_step_end(ticket, 2, 0, params[:, :, 2 * C:], y_hat, yh, yw, C)
         sp = self._spatial_prior(y_hat, params)
         self._decode_step(2, 1, sp[:, :, :C], sp[:, :, C:], y_hat, yh, yw, C, "p1")
         self._prior_finish(0, y_hat, params[:, :, :C])
