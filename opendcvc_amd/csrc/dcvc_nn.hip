@@ -190,7 +190,10 @@ struct TailParams {
         }                                                            \
     } while (0)
 
-constexpr int DW_SLAB = 64;   // channels per depthwise slab staged in LDS (with its 1-pixel halo)
+// channels per depthwise slab staged in LDS (with its 1-pixel halo): 128 in fp16 (widths that are
+// multiples of 128), else 64
+template <typename T>
+__host__ __device__ constexpr int dw_slab_max() { return sizeof(T) == 2 ? 128 : 64; }
 
 template <int MT, int NTW>
 struct TailCfg {   // small blocks run two workgroups per CU (<= 256 VGPRs): shallower prefetch, narrower FFN chunk
@@ -204,7 +207,7 @@ struct TailLds {
     static constexpr int M = Tile<MT>::M;
     static constexpr int VC = NWAVE * NTV * 16;
     static constexpr int HALO = (Tile<MT>::TH + 2) * (Tile<MT>::TW + 2);
-    static constexpr int lds_slab = DW_SLAB + TR::kPad;
+    static constexpr int lds_slab = dw_slab_max<T>() + TR::kPad;
     static constexpr int ldv = VC + TR::kPad;
     static constexpr size_t v_elems = (size_t)M * ldv > (size_t)HALO * lds_slab ? (size_t)M * ldv : (size_t)HALO * lds_slab;
     static size_t bytes(int C) { return ((size_t)M * (C + TR::kPad) + v_elems) * sizeof(T); }
@@ -247,6 +250,7 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
     {   // depthwise 3x3 (zero padding), taps in (ky,kx) order, + bias.  The activation tile and its
         // 1-pixel halo go through LDS one 64-channel slab at a time (each input element is fetched
         // from L2 1.4-1.6x instead of 9x); the next slab is prefetched into registers meanwhile.
+        constexpr int DW_SLAB = (dw_slab_max<T>() == 128 && NTW % 2 == 0) ? 128 : 64;
         constexpr int HW_ = TW + 2, HALO = LD::HALO, GS = DW_SLAB / V, lds_s = LD::lds_slab;
         constexpr int NLD = (HALO * GS + NTHREADS - 1) / NTHREADS;
         const T* wd = reinterpret_cast<const T*>(p.wd);
@@ -463,6 +467,10 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
             o[5] = tg4;         // FFN GEMM4
             o[6] = te - ts4;    // final epilogue + store
             o[7] = te - ts0;    // total
+            if (p.ablate & 16) {   // diagnostic: absolute start / end stamps instead of two phase counters
+                o[0] = ts0;
+                o[1] = te;
+            }
         }
     }
 }
@@ -765,6 +773,25 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
                 fprintf(stderr, " %s=%llu", names[k], v[grid / 2]);
             }
             fprintf(stderr, "\n");
+            if (tp.ablate & 16) {
+                unsigned long long t0 = ~0ull, t1 = 0;
+                for (int b = 0; b < grid; ++b) {
+                    t0 = std::min(t0, hs[(size_t)b * 8]);
+                    t1 = std::max(t1, hs[(size_t)b * 8 + 1]);
+                }
+                std::vector<unsigned long long> st(grid), en(grid), du(grid);
+                for (int b = 0; b < grid; ++b) {
+                    st[b] = hs[(size_t)b * 8] - t0;
+                    en[b] = hs[(size_t)b * 8 + 1] - t0;
+                    du[b] = hs[(size_t)b * 8 + 7];
+                }
+                std::sort(st.begin(), st.end());
+                std::sort(en.begin(), en.end());
+                std::sort(du.begin(), du.end());
+                fprintf(stderr, "[span %llu] start min/med/p90/max %llu %llu %llu %llu | end med/p90/max %llu %llu %llu | dur min/med/p90/max %llu %llu %llu %llu\n",
+                        t1 - t0, st[0], st[grid / 2], st[grid * 9 / 10], st[grid - 1], en[grid / 2], en[grid * 9 / 10],
+                        en[grid - 1], du[0], du[grid / 2], du[grid * 9 / 10], du[grid - 1]);
+            }
         }
     }
     return 0;

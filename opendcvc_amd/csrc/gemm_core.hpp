@@ -126,14 +126,14 @@ __device__ __forceinline__ void gemm_run(floatx4 (&acc)[MT][NT], const T* X, int
                 frag_t x[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) x[m] = *reinterpret_cast<const frag_t*>(x_base + m * 16 * ldx + g * KG);
+                const int gn = g + PF;
 #pragma unroll
-                for (int i = 0; i < NT; ++i)
+                for (int i = 0; i < NT; ++i) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m) acc[m][i] = Traits<T>::mma(pre.w[s][i], x[m], acc[m][i]);
-                const int gn = g + PF;
-                if (gn < kgs) {
-#pragma unroll
-                    for (int i = 0; i < NT; ++i) pre.w[s][i] = w_base[i][(size_t)gn * 64];
+                    // refill this fragment's registers right after its last use (not after the whole
+                    // group): almost PF full groups of MFMA time cover the L2 latency instead of PF-1
+                    if (gn < kgs) pre.w[s][i] = w_base[i][(size_t)gn * 64];
                 }
             }
         }
