@@ -37,7 +37,38 @@ def run(C, H, W, dtype=torch.float16, iters=30):
     flop = 2.0 * H * W * (7 * C * C + 9 * C)
     print(f"C={C} {H}x{W} {dtype}: head {head.value*1e3:.1f} us  tail {tail.value*1e3:.1f} us  tail {flop/tail.value/1e9:.1f} TFLOP/s  ablate={os.environ.get('DCVC_ABLATE','0')}", flush=True)
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "conv"):
     shapes = [(256, 136, 240), (256, 68, 120), (384, 68, 120), (128, 17, 30), (320, 136, 240)]
     for C, H, W in shapes if len(sys.argv) < 2 else [tuple(int(v) for v in sys.argv[1:4])]:
         run(C, H, W)
+
+
+def run_conv(cin, cout, k, stride, pad, epi, H, W, dtype=torch.float16, iters=30):
+    rng = np.random.default_rng(0)
+    sd = {"m.weight": (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32),
+          "m.bias": (rng.standard_normal(cout) * 0.1).astype(np.float32)}
+    conv = L.Conv2d(sd, "m", dtype, stride, pad, epi)
+    x = (torch.randn((H, W, conv.cin_p), device="cuda") * 0.5).to(dtype)
+    q = torch.ones(cout, device="cuda")
+    out = conv(x, quant=q if epi == 1 else None)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        conv(x, quant=q if epi == 1 else None, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    Ho, Wo = conv.out_hw(H, W)
+    if epi == 2:
+        Ho, Wo = Ho // 2, Wo // 2
+    flop = 2.0 * Ho * Wo * cin * cout * k * k
+    print(f"conv {cin}->{cout} k{k} s{stride} epi{epi} {H}x{W}: {ms*1e3:.1f} us  {flop/ms/1e9:.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "conv":
+    for args in [(128, 1024, 3, 1, 1, 2, 68, 120), (256, 128, 3, 2, 1, 0, 136, 240), (384, 384, 1, 1, 0, 0, 68, 120),
+                 (384, 256, 1, 1, 0, 0, 68, 120), (256, 256, 2, 2, 0, 0, 136, 240), (256, 256, 1, 1, 0, 1, 136, 240),
+                 (192, 256, 1, 1, 0, 0, 136, 240), (320, 192, 1, 1, 0, 0, 136, 240), (128, 512, 1, 1, 0, 2, 17, 30),
+                 (128, 128, 2, 2, 0, 0, 68, 120)]:
+        run_conv(*args)
