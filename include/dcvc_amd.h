@@ -97,6 +97,17 @@ int dcvc_unshuffle8(int dtype, const void* x_nchw, int C, int H, int W, void* ou
  * bias_pixel_shuffle_8 (cuda_inference.py:182-193, kernel.cu:763); bias may be NULL. */
 int dcvc_shuffle8_clamp(int dtype, const void* x_hwc, int64_t ld, const float* bias, int C, int H,
                         int W, int do_clamp, void* out_nchw, void* stream);
+/* Frame I/O fused into one pass each.
+ * Planar 8-bit YUV 4:2:0 -> the padded YCbCr 4:4:4 model input [3][H+pad_b][W+pad_r]: nearest chroma
+ * upsampling (src/utils/transforms.py:13-24), /255 and cast (test_video.py:60-63,90), replicate pad
+ * (test_video.py:179). */
+int dcvc_yuv420_to_frame(int dtype, const uint8_t* y, const uint8_t* u, const uint8_t* v, int H, int W,
+                         int pad_b, int pad_r, void* out_nchw, void* stream);
+/* Reconstruction [3][Hp][Wp] -> planar 8-bit YUV 4:2:0 of the HxW picture (test_video.py:307-311):
+ * crop, chroma 2x2 mean (transforms.py:56-63), clamp(x*255, 0, 255); Y rounded, U/V truncated like
+ * the reference's `.to(uint8)` unless round_uv. */
+int dcvc_frame_to_yuv420(int dtype, const void* x_nchw, int Hp, int Wp, int H, int W, int round_uv,
+                         uint8_t* y, uint8_t* u, uint8_t* v, void* stream);
 /* right/bottom edge replication on HWC: replicate_pad (cuda_inference.py:174-179), pad_for_y */
 int dcvc_replicate_pad_hwc(int dtype, const void* x, int64_t ldx, int H, int W, int C, int pad_b,
                            int pad_r, void* out, int64_t ldo, void* stream);

@@ -133,6 +133,51 @@ __global__ void hwc_to_nchw_kernel(const T* x, int64_t ldx, int C, int64_t HW, T
     out[i] = x[p * ldx + c];
 }
 
+
+// ------------------------------------------------------------------ YUV 4:2:0 <-> model frame
+template <typename T>
+__global__ void yuv420_to_frame_kernel(const uint8_t* yp, const uint8_t* up, const uint8_t* vp, int H, int W, int HO,
+                                       int WO, T* out)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= (int64_t)3 * HO * WO) return;
+    const int xw = (int)(i % WO), y = (int)((i / WO) % HO), c = (int)(i / ((int64_t)WO * HO));
+    const int sy = y < H ? y : H - 1, sx = xw < W ? xw : W - 1;        // replicate pad of the 4:4:4 frame
+    int v;
+    if (c == 0)
+        v = yp[(int64_t)sy * W + sx];
+    else
+        v = (c == 1 ? up : vp)[(int64_t)(sy >> 1) * (W >> 1) + (sx >> 1)];   // nearest chroma upsampling
+    st(out, i, (float)v / 255.0f);
+}
+
+template <typename T>
+__global__ void frame_to_yuv420_kernel(const T* x, int HP, int WP, int H, int W, int round_uv, uint8_t* yp, uint8_t* up,
+                                       uint8_t* vp)
+{
+    const int64_t ny = (int64_t)H * W, nc = (int64_t)(H >> 1) * (W >> 1);
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= ny + 2 * nc) return;
+    if (i < ny) {
+        const int xw = (int)(i % W), y = (int)(i / W);
+        const float s = (float)(T)(ld(x, (int64_t)y * WP + xw) * 255.0f);   // product rounded to the storage type, as torch does
+        yp[i] = (uint8_t)dcvc_roundf(clampf(s, 0.f, 255.f));
+        return;
+    }
+    const int64_t j = i - ny;
+    const int c = j < nc ? 1 : 2;
+    const int64_t k = c == 1 ? j : j - nc;
+    const int w2 = W >> 1;
+    const int xw = (int)(k % w2), y = (int)(k / w2);
+    const T* pl = x + (int64_t)c * HP * WP;
+    const float a = ld(pl, (int64_t)(2 * y) * WP + 2 * xw), b = ld(pl, (int64_t)(2 * y) * WP + 2 * xw + 1);
+    const float d = ld(pl, (int64_t)(2 * y + 1) * WP + 2 * xw), e = ld(pl, (int64_t)(2 * y + 1) * WP + 2 * xw + 1);
+    const float m = (float)(T)(((a + b) + (d + e)) * 0.25f);                 // avg_pool2d(2) result in the storage type
+    float s = clampf((float)(T)(m * 255.0f), 0.f, 255.f);
+    if (round_uv) s = dcvc_roundf(s);
+    (c == 1 ? up : vp)[k] = (uint8_t)s;                                      // truncation like `.to(uint8)`
+}
+
 // ------------------------------------------------------------------ z quantiser
 template <typename T>
 __global__ void round_z_kernel(T* z, int64_t ldz, int64_t HW, int C, int8_t* z_chw)
@@ -625,6 +670,31 @@ int dcvc_prior_finish(int dtype, int q_mode, void* yhat, int64_t ldh, const void
         using T = decltype(tag);
         prior_finish_kernel<T><<<nblocks((int64_t)H * W * C), EB, 0, (hipStream_t)stream>>>(q_mode, (T*)yhat, ldh, (const T*)qsrc, ldq,
                      (int64_t)H * W, C);
+    });
+}
+
+
+int dcvc_yuv420_to_frame(int dtype, const uint8_t* y, const uint8_t* u, const uint8_t* v, int H, int W, int pad_b,
+                         int pad_r, void* out_nchw, void* stream)
+{
+    DCVC_REQUIRE(y && u && v && out_nchw && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && pad_b >= 0 && pad_r >= 0,
+                 "dcvc_yuv420_to_frame: bad arguments (%dx%d)", H, W);
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        yuv420_to_frame_kernel<T><<<nblocks((int64_t)3 * (H + pad_b) * (W + pad_r)), EB, 0, (hipStream_t)stream>>>(
+            y, u, v, H, W, H + pad_b, W + pad_r, (T*)out_nchw);
+    });
+}
+
+int dcvc_frame_to_yuv420(int dtype, const void* x_nchw, int Hp, int Wp, int H, int W, int round_uv, uint8_t* y,
+                         uint8_t* u, uint8_t* v, void* stream)
+{
+    DCVC_REQUIRE(x_nchw && y && u && v && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Hp >= H && Wp >= W,
+                 "dcvc_frame_to_yuv420: bad arguments");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        frame_to_yuv420_kernel<T><<<nblocks((int64_t)H * W * 3 / 2), EB, 0, (hipStream_t)stream>>>(
+            (const T*)x_nchw, Hp, Wp, H, W, round_uv, y, u, v);
     });
 }
 

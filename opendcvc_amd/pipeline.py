@@ -64,6 +64,42 @@ class SequenceDecoder:
         return dec["x_hat"]
 
 
+def load_yuv420_frame(y, u, v, dtype, pad_to=16):
+    """uint8 CUDA planes y [H,W], u/v [H/2,W/2] -> padded model input [1,3,H',W'] (one fused kernel;
+    reference: get_src_frame + replicate_pad, test_video.py:74-91,150,179)."""
+    import ctypes
+    import torch
+    from . import _lib
+    from . import nn as L
+    H, W = y.shape
+    pr, pb = (-W) % pad_to, (-H) % pad_to
+    out = torch.empty((1, 3, H + pb, W + pr), dtype=dtype, device=y.device)
+    _lib.check(_lib.lib().dcvc_yuv420_to_frame(L.dtype_code(dtype), L._p(y.contiguous()), L._p(u.contiguous()),
+                                               L._p(v.contiguous()), H, W, pb, pr, L._p(out),
+                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+               "dcvc_yuv420_to_frame")
+    return out
+
+
+def store_yuv420_frame(x_hat, height, width, round_uv=False):
+    """decoded [1,3,H',W'] -> uint8 CUDA planes (y, u, v) of the height x width picture
+    (reference: yuv_444_to_420 + clamp*255 + uint8, test_video.py:307-311)."""
+    import ctypes
+    import torch
+    from . import _lib
+    from . import nn as L
+    x = x_hat.contiguous()
+    _, _, Hp, Wp = x.shape
+    y = torch.empty((height, width), dtype=torch.uint8, device=x.device)
+    u = torch.empty((height // 2, width // 2), dtype=torch.uint8, device=x.device)
+    v = torch.empty_like(u)
+    _lib.check(_lib.lib().dcvc_frame_to_yuv420(L.dtype_code(x.dtype), L._p(x), Hp, Wp, height, width, int(round_uv),
+                                               L._p(y), L._p(u), L._p(v),
+                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+               "dcvc_frame_to_yuv420")
+    return y, u, v
+
+
 def use_two_entropy_coders(height, width):
     """test_video.py:152"""
     return height * width > 1280 * 720
