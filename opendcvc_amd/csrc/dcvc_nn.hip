@@ -195,17 +195,19 @@ struct TailParams {
 template <typename T>
 __host__ __device__ constexpr int dw_slab_max() { return sizeof(T) == 2 ? 128 : 64; }
 
-template <int MT, int NTW>
-struct TailCfg {   // small blocks run two workgroups per CU (<= 256 VGPRs): shallower prefetch, narrower FFN chunk
-    static constexpr bool two_per_cu = (MT <= 4 && NTW <= 4);
+template <int MT, int NTW, int NW>
+struct TailCfg {   // small blocks run two workgroups per CU: shallower prefetch, narrower FFN chunk.
+                   // NW = waves per workgroup (4, or 8: more waves per SIMD hide latency by switching waves)
+    static constexpr bool two_per_cu = (MT <= 4 && NTW * NW <= 16);
     static constexpr int NTV = two_per_cu ? 1 : 2;
+    static constexpr int waves_per_simd = (two_per_cu ? 2 : 1) * NW / 4;
 };
 
-template <typename T, int MT, int NTV>
+template <typename T, int MT, int NTV, int NW>
 struct TailLds {
     using TR = Traits<T>;
     static constexpr int M = Tile<MT>::M;
-    static constexpr int VC = NWAVE * NTV * 16;
+    static constexpr int VC = NW * NTV * 16;
     static constexpr int HALO = (Tile<MT>::TH + 2) * (Tile<MT>::TW + 2);
     static constexpr int lds_slab = dw_slab_max<T>() + TR::kPad;
     static constexpr int ldv = VC + TR::kPad;
@@ -213,17 +215,18 @@ struct TailLds {
     static size_t bytes(int C) { return ((size_t)M * (C + TR::kPad) + v_elems) * sizeof(T); }
 };
 
-template <typename T, int MT, int NTW>
-__global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) void dcb_tail_kernel(TailParams p)
+template <typename T, int MT, int NTW, int NW>
+__global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) void dcb_tail_kernel(TailParams p)
 {
     using TR = Traits<T>;
     using frag_t = typename TR::frag_t;
-    constexpr int NTV = TailCfg<MT, NTW>::NTV;    // v tiles per wave per chunk
-    using LD = TailLds<T, MT, NTV>;
+    constexpr int NTV = TailCfg<MT, NTW, NW>::NTV;
+    constexpr int NTHREADS_ = NW * 64;    // v tiles per wave per chunk
+    using LD = TailLds<T, MT, NTV, NW>;
     constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH, V = TR::kVec;
-    constexpr int PF = TailCfg<MT, NTW>::two_per_cu ? 2 : Pf<T>::value;
-    constexpr int PF3 = (sizeof(T) == 2 && NTV == 1) ? 4 : PF;   // GEMM3 has few MFMAs per k-group: look further ahead
-    constexpr int VC = NWAVE * NTV * 16;          // v columns per chunk
+    constexpr int PF = TailCfg<MT, NTW, NW>::two_per_cu ? 2 : Pf<T>::value;
+    constexpr int PF3 = (sizeof(T) == 2 && NTV == 1 && NW == 4) ? 4 : PF;   // GEMM3 has few MFMAs per k-group: look further ahead
+    constexpr int VC = NW * NTV * 16;          // v columns per chunk
     static_assert(VC == LD::VC, "chunk width");
     extern __shared__ __attribute__((aligned(32))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -243,23 +246,23 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
     const int pl = lane & 15, cq = (lane >> 4) * 4;
     int tiles[NTW];
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) tiles[i] = wave + NWAVE * i;
+    for (int i = 0; i < NTW; ++i) tiles[i] = wave + NW * i;
     WPre<T, NTW, PF> pre2;   // W2's first groups are requested now and land during the depthwise stage
     gemm_prefetch<T, NTW, PF>(pre2, C / KG, reinterpret_cast<const frag_t*>(p.w2), C / KG, 0, tiles, lane);
 
     {   // depthwise 3x3 (zero padding), taps in (ky,kx) order, + bias.  The activation tile and its
         // 1-pixel halo go through LDS one 64-channel slab at a time (each input element is fetched
         // from L2 1.4-1.6x instead of 9x); the next slab is prefetched into registers meanwhile.
-        constexpr int DW_SLAB = (dw_slab_max<T>() == 128 && NTW % 2 == 0) ? 128 : 64;
+        constexpr int DW_SLAB = (dw_slab_max<T>() == 128 && (NTW * NW) % 8 == 0) ? 128 : 64;
         constexpr int HW_ = TW + 2, HALO = LD::HALO, GS = DW_SLAB / V, lds_s = LD::lds_slab;
-        constexpr int NLD = (HALO * GS + NTHREADS - 1) / NTHREADS;
+        constexpr int NLD = (HALO * GS + NTHREADS_ - 1) / NTHREADS_;
         const T* wd = reinterpret_cast<const T*>(p.wd);
         const int nslab = C / DW_SLAB;
         Vec16 pre[NLD];
         auto fetch = [&](int slab) {
 #pragma unroll
             for (int k = 0; k < NLD; ++k) {
-                const int it = tid + k * NTHREADS;
+                const int it = tid + k * NTHREADS_;
                 Vec16 v = VEC16_ZERO;
                 if (it < HALO * GS) {
                     const int hp = it / GS, c = slab * DW_SLAB + (it - hp * GS) * V;
@@ -274,13 +277,13 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
         for (int slab = 0; slab < nslab; ++slab) {
 #pragma unroll
             for (int k = 0; k < NLD; ++k) {
-                const int it = tid + k * NTHREADS;
+                const int it = tid + k * NTHREADS_;
                 if (it < HALO * GS) {
                     const int hp = it / GS, cs = (it - hp * GS) * V;
                     *reinterpret_cast<Vec16*>(bufV + hp * lds_s + cs) = pre[k];   // natural order inside the slab
                 }
             }
-            // a thread always works on the same channel group of a slab (NTHREADS % GS == 0): its 9 tap
+            // a thread always works on the same channel group of a slab (NTHREADS_ % GS == 0): its 9 tap
             // weights and the bias are fetched once per slab, before the barrier
             const int cs = (tid % GS) * V, c = slab * DW_SLAB + cs;
             Vec16 wtap[9];
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
             }
             __syncthreads();
             if (slab + 1 < nslab) fetch(slab + 1);
-            for (int m = tid / GS; m < M; m += NTHREADS / GS) {
+            for (int m = tid / GS; m < M; m += NTHREADS_ / GS) {
                 const int my = m / TW, mx = m % TW;
                 float s[V];
 #pragma unroll
@@ -320,11 +323,11 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
     STAMP(ts1);
 
     // identity rows for the o = ... + x' pass: requested before GEMM2 so they arrive underneath it
-    constexpr int NID = (M * (64 * NTW / V) + NTHREADS - 1) / NTHREADS;
+    constexpr int NID = (M * (16 * NW * NTW / V) + NTHREADS_ - 1) / NTHREADS_;
     Vec16 idv[NID];
 #pragma unroll
     for (int k = 0; k < NID; ++k) {
-        const int it = tid + k * NTHREADS;
+        const int it = tid + k * NTHREADS_;
         const int m = it / GC, c = (it - m * GC) * V;
         const int y = ty0 + m / TW, x = tx0 + m % TW;
         idv[k] = VEC16_ZERO;
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
     // o = (W2 d + b2) + x'   (identity rows were loaded with coalesced 16-byte loads above)
 #pragma unroll
     for (int k = 0; k < NID; ++k) {
-        const int it = tid + k * NTHREADS;
+        const int it = tid + k * NTHREADS_;
         if (it < M * GC) {
             const int m = it / GC, c = (it - m * GC) * V;
             float o[V], id[V];
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
     STAMP(ts3);
     // FFN: C -> 4C -> chunk-add -> 2C -> C, the 4C-wide intermediate never leaves the CU
     zero_acc(acc);
-    const int chunks = vtiles / (NWAVE * NTV);
+    const int chunks = vtiles / (NW * NTV);
     for (int ch = 0; ch < chunks; ++ch) {
         floatx4 u[MT][2 * NTV];
         zero_acc(u);
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
                                      ch * (VC / KG), tiles, lane);
         if (ch + 1 < chunks) {   // next chunk's first W3 groups, requested before the barrier
 #pragma unroll
-            for (int j = 0; j < 2 * NTV; ++j) ut[j] += NWAVE * NTV;
+            for (int j = 0; j < 2 * NTV; ++j) ut[j] += NW * NTV;
             gemm_prefetch<T, 2 * NTV, PF3>(pre3, C / KG, reinterpret_cast<const frag_t*>(p.w3), C / KG, 0, ut, lane);
         }
         __syncthreads();
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(NTHREADS, (TailCfg<MT, NTW>::two_per_cu ? 2 : 1)) v
     }
     __syncthreads();
     T* out = reinterpret_cast<T*>(p.out);
-    for (int it = tid; it < M * GC; it += NTHREADS) {
+    for (int it = tid; it < M * GC; it += NTHREADS_) {
         const int m = it / GC, c = (it - m * GC) * V;
         const int y = ty0 + m / TW, x = tx0 + m % TW;
         if (y < p.H && x < p.W) {
@@ -664,10 +667,20 @@ size_t head_lds(int kin, int c, bool adapt)
     const int kx = kin > c ? kin : c;
     return (size_t)Tile<MT>::M * ((kx + Traits<T>::kPad) + (adapt ? c + Traits<T>::kPad : 0)) * sizeof(T);
 }
-template <typename T, int MT, int NTW>
+template <typename T, int MT, int NTW, int NW>
 size_t tail_lds(int c)
 {
-    return TailLds<T, MT, TailCfg<MT, NTW>::NTV>::bytes(c);
+    return TailLds<T, MT, TailCfg<MT, NTW, NW>::NTV, NW>::bytes(c);
+}
+
+template <typename T, int MT, int NTW, int NW>
+int launch_tail(const TailParams& tp, int grid, int C, hipStream_t st)
+{
+    const size_t lds = tail_lds<T, MT, NTW, NW>(C);
+    int rc = set_lds(dcb_tail_kernel<T, MT, NTW, NW>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((dcb_tail_kernel<T, MT, NTW, NW>), dim3(grid), dim3(NW * 64), lds, st, tp);
+    return 0;
 }
 
 template <typename K>
@@ -751,10 +764,12 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         DCVC_HIP(hipMalloc(&d_stamps, (size_t)grid * 8 * sizeof(unsigned long long)));
         tp.stamps = d_stamps;
     }
-    const size_t lds = tail_lds<T, MT, NTW>(C);
-    int rc = set_lds(dcb_tail_kernel<T, MT, NTW>, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL((dcb_tail_kernel<T, MT, NTW>), dim3(grid), dim3(NTHREADS), lds, st, tp);
+    {
+        // (an eight-wave variant, NW = 8, was measured in round 1: 116 us vs 63 us - at <= 128 VGPRs the
+        // block spills; the kernel stays templated on NW for a register-frugal rewrite)
+        const int rc = launch_tail<T, MT, NTW, 4>(tp, grid, C, st);
+        if (rc) return rc;
+    }
     DCVC_LAUNCH_CHECK();
     if (ev) DCVC_HIP(hipEventRecord(ev[2], st));
     if (want_stamps) {   // diagnostic only: median cycles per phase over the workgroups
