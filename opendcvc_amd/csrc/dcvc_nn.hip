@@ -27,7 +27,7 @@ struct Tile {
 
 template <typename T>
 struct Pf {   // weight prefetch depth (reduction groups in flight per wave)
-    static constexpr int value = sizeof(T) == 2 ? 3 : 2;
+    static constexpr int value = sizeof(T) == 2 ? 4 : 2;   // even: gemm_run double-buffers by parity
 };
 
 struct SrcPair {   // channel-concat of up to two HWC sources
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
     constexpr int NTHREADS_ = NW * 64;    // v tiles per wave per chunk
     using LD = TailLds<T, MT, NTV, NW>;
     constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH, V = TR::kVec;
-    constexpr int PF = TailCfg<MT, NTW, NW>::two_per_cu ? 2 : Pf<T>::value;
+    constexpr int PF = (TailCfg<MT, NTW, NW>::two_per_cu || (NTW * NW / 4) % 2 != 0) ? 2 : Pf<T>::value;   // divides the k-group count
     constexpr int PF3 = (sizeof(T) == 2 && NTV == 1 && NW == 4) ? 4 : PF;   // GEMM3 has few MFMAs per k-group: look further ahead
     constexpr int VC = NW * NTV * 16;          // v columns per chunk
     static_assert(VC == LD::VC, "chunk width");

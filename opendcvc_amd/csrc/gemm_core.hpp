@@ -118,26 +118,42 @@ __device__ __forceinline__ void gemm_run(floatx4 (&acc)[MT][NT], const T* X, int
     const frag_t* w_base[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) w_base[i] = Wp + ((size_t)tiles[i] * kgs_total + kg0) * 64 + lane;
-    for (int g0 = 0; g0 < kgs; g0 += PF) {
+
+    // One k-group: MFMAs of fragment i, then refill its registers right away with group g + PF.
+    // The refill is UNCONDITIONAL (index clamped to the last group): a branch around a global load
+    // makes hipcc give up counting and emit s_waitcnt vmcnt(0) at the loop head, which waits for the
+    // loads issued one step earlier, i.e. exposes the full L2 latency in every step (measured: the
+    // GEMM phases ran at a quarter of the MFMA issue rate).
+    auto step = [&](int g, int s) __attribute__((always_inline)) {
+        frag_t x[MT];
 #pragma unroll
-        for (int s = 0; s < PF; ++s) {
-            const int g = g0 + s;
-            if (g < kgs) {
-                frag_t x[MT];
+        for (int m = 0; m < MT; ++m) x[m] = *reinterpret_cast<const frag_t*>(x_base + m * 16 * ldx + g * KG);
+        const int gn = (g + PF < kgs) ? g + PF : kgs - 1;
 #pragma unroll
-                for (int m = 0; m < MT; ++m) x[m] = *reinterpret_cast<const frag_t*>(x_base + m * 16 * ldx + g * KG);
-                const int gn = g + PF;
+        for (int i = 0; i < NT; ++i) {
 #pragma unroll
-                for (int i = 0; i < NT; ++i) {
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m][i] = Traits<T>::mma(pre.w[s][i], x[m], acc[m][i]);
-                    // refill this fragment's registers right after its last use (not after the whole
-                    // group): almost PF full groups of MFMA time cover the L2 latency instead of PF-1
-                    if (gn < kgs) pre.w[s][i] = w_base[i][(size_t)gn * 64];
-                }
-            }
+            for (int m = 0; m < MT; ++m) acc[m][i] = Traits<T>::mma(pre.w[s][i], x[m], acc[m][i]);
+            pre.w[s][i] = w_base[i][(size_t)gn * 64];
         }
+        // pin the interleave: [LDS reads] then per fragment [its MFMAs][its refill].  Left alone, the
+        // scheduler sinks all refills to the end of the loop body and the next iteration waits on them.
+        // (Double-buffering the pixel fragments as well was measured: no gain at two waves per SIMD.)
+        constexpr int kMfmaPerMma = sizeof(T) == 2 ? 1 : 8, kVecPerFrag = sizeof(T) == 2 ? 1 : 2;
+        __builtin_amdgcn_sched_group_barrier(0x100, MT * kVecPerFrag, 0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * kMfmaPerMma, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, kVecPerFrag, 0);
+        }
+    };
+    const int kfull = (kgs / PF) * PF;
+    for (int g0 = 0; g0 < kfull; g0 += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) step(g0 + s, s);
     }
+#pragma unroll
+    for (int s = 0; s < PF - 1; ++s)        // remainder groups (kgs % PF), outside the hot loop
+        if (kfull + s < kgs) step(kfull + s, s);
 }
 
 template <typename T, int MT, int NT, int PF>
