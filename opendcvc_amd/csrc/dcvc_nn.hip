@@ -27,7 +27,7 @@ struct Tile {
 
 template <typename T>
 struct Pf {   // weight prefetch depth (reduction groups in flight per wave)
-    static constexpr int value = sizeof(T) == 2 ? 4 : 2;   // even: gemm_run double-buffers by parity
+    static constexpr int value = 2;   // divides every k-group count (C is a multiple of 64); deeper rings only cost registers
 };
 
 struct SrcPair {   // channel-concat of up to two HWC sources
@@ -224,8 +224,8 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
     constexpr int NTHREADS_ = NW * 64;    // v tiles per wave per chunk
     using LD = TailLds<T, MT, NTV, NW>;
     constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH, V = TR::kVec;
-    constexpr int PF = (TailCfg<MT, NTW, NW>::two_per_cu || (NTW * NW / 4) % 2 != 0) ? 2 : Pf<T>::value;   // divides the k-group count
-    constexpr int PF3 = (sizeof(T) == 2 && NTV == 1 && NW == 4) ? 4 : PF;   // GEMM3 has few MFMAs per k-group: look further ahead
+    constexpr int PF = Pf<T>::value;
+    constexpr int PF3 = PF;   // GEMM3 has few MFMAs per k-group: look further ahead
     constexpr int VC = NW * NTV * 16;          // v columns per chunk
     static_assert(VC == LD::VC, "chunk width");
     extern __shared__ __attribute__((aligned(32))) char smem[];
@@ -816,14 +816,6 @@ template <typename T, int MT>
 int dispatch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float* quant, void* out, int64_t ldo,
                  void* scratch, hipStream_t st, hipEvent_t* ev = nullptr)
 {
-    if constexpr (MT >= 8) {   // 128-pixel tiles: only the widths whose accumulators fit (<= 320 channels)
-        switch (h->c_p / 64) {
-        case 2: return launch_dcb<T, MT, 2>(h, src, H, W, quant, out, ldo, scratch, st, ev);
-        case 4: return launch_dcb<T, MT, 4>(h, src, H, W, quant, out, ldo, scratch, st, ev);
-        case 5: return launch_dcb<T, MT, 5>(h, src, H, W, quant, out, ldo, scratch, st, ev);
-        default: dcvc::set_error("DepthConvBlock width %d has no 128-pixel variant", h->c_p); return dcvc::E_ARG;
-        }
-    }
     switch (h->c_p / 64) {
     case 1: return launch_dcb<T, MT, 1>(h, src, H, W, quant, out, ldo, scratch, st, ev);
     case 2: return launch_dcb<T, MT, 2>(h, src, H, W, quant, out, ldo, scratch, st, ev);
@@ -859,12 +851,14 @@ int dispatch_conv(const dcvc_conv* h, const ConvParams& cp, hipStream_t st)
 }
 
 
-// Pixel-tile height selection (f16): 16*MT pixels per workgroup.  Small feature maps take smaller
-// tiles so that the grid still covers the 256 CUs; DCVC_MT overrides for experiments.
+// Pixel-tile selection (f16): 16*MT pixels per workgroup.  Small feature maps take 32-pixel tiles so
+// that the grid still covers the 256 CUs (measured: 68x120 maps 15-25 % faster); 128-pixel tiles
+// (MT = 8, one workgroup per CU) were measured slower than 64-pixel tiles at two workgroups per CU
+// (80 vs 63 us at C = 256, 136x240) and are not instantiated.  DCVC_MT overrides for experiments.
 static int pick_mt_f16(int H, int W, int c_p)
 {
     static const int forced = getenv("DCVC_MT") ? atoi(getenv("DCVC_MT")) : 0;
-    if (forced == 2 || forced == 4 || (forced == 8 && c_p <= 320)) return forced;
+    if (forced == 2 || forced == 4) return forced;
     const long P = (long)H * W;
     (void)c_p;
     return P >= 12000 ? 4 : 2;
@@ -883,7 +877,6 @@ static int run_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const fl
     if (h->dtype != DCVC_F16) return dispatch_dcb<float, 2>(h, src, H, W, quant, out, ldo, scratch, st, ev);
     switch (pick_mt_f16(H, W, h->c_p)) {
     case 2: return dispatch_dcb_f16<2>(h, src, H, W, quant, out, ldo, scratch, st, ev);
-    case 8: return dispatch_dcb_f16<8>(h, src, H, W, quant, out, ldo, scratch, st, ev);
     default: return dispatch_dcb_f16<4>(h, src, H, W, quant, out, ldo, scratch, st, ev);
     }
 }
