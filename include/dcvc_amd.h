@@ -201,7 +201,8 @@ int dcvc_hwc_to_nchw(int dtype, const void* x, int64_t ldx, int C, int64_t HW, v
  * Host entropy coder (rANS).  Replaces MLCodec_extensions_cpp (src/cpp/py_rans/py_rans.cpp:14-393,
  * rans.cpp:60-534); the byte stream is identical to the reference's.  One worker thread per
  * coder half, like RansEncoderLibMultiThread / RansDecoderLibMultiThread; calls enqueue and
- * return, dcvc_rans_get_* block.  Input buffers are copied on entry. */
+ * return, dcvc_rans_get_* block.  Input buffers are copied on entry unless the entry point says
+ * otherwise (*_borrowed, decode_and_get_y). */
 typedef struct dcvc_rans_enc dcvc_rans_enc;
 typedef struct dcvc_rans_dec dcvc_rans_dec;
 dcvc_rans_enc* dcvc_rans_enc_create(void);
@@ -214,6 +215,9 @@ int dcvc_rans_enc_reset(dcvc_rans_enc*);
 /* symbols: (int8 symbol << 8) + uint8 cdf index (encode_y, py_rans.cpp:20-41).
  * Entries whose low byte is 0xFF are dropped first (see dcvc_prior_enc_step). */
 int dcvc_rans_enc_encode_y(dcvc_rans_enc*, const int16_t* symbols, int64_t n, int group);
+/* same, without the copy: `symbols` must stay valid and unchanged until dcvc_rans_enc_get_stream
+ * has returned (the pinned staging buffer of the D2H hand-off qualifies) */
+int dcvc_rans_enc_encode_y_borrowed(dcvc_rans_enc*, const int16_t* symbols, int64_t n, int group);
 int dcvc_rans_enc_encode_z(dcvc_rans_enc*, const int8_t* symbols, int64_t n, int group,
                            int start_offset, int per_channel_size);
 int dcvc_rans_enc_flush(dcvc_rans_enc*);
@@ -234,6 +238,11 @@ int dcvc_rans_dec_decode_z(dcvc_rans_dec*, int64_t total, int group, int start_o
                            int per_channel_size);
 /* blocks; copies the decoded int8 symbols of the last decode_* call into out[0..n) */
 int64_t dcvc_rans_dec_get(dcvc_rans_dec*, int8_t* out, int64_t capacity);
+/* decode_and_get_y (py_rans.cpp:175-262 decode_y + get_decoded_tensor in one call): synchronous,
+ * no staging copies - reads `indexes` and writes out[0..n) directly; the first coder runs on the
+ * calling thread, the second on its worker. */
+int dcvc_rans_dec_decode_and_get_y(dcvc_rans_dec*, const uint8_t* indexes, int64_t n, int group,
+                                   int8_t* out);
 /* pmf_to_quantized_cdf (py_rans.cpp:307-364); out holds n+1 entries */
 int dcvc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, uint32_t* out);
 

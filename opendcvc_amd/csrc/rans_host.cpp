@@ -40,25 +40,35 @@ constexpr uint32_t kMask = (1u << kScaleBits) - 1;
 // Per-table data laid out for the hot loops:
 //   encoder: per (table, value) the ryg_rans "fast encode" constants (reciprocal multiply instead of
 //            a division; bit-identical to ((x / f) << 16) + x % f + start for 31-bit states);
-//   decoder: the cdf as 32 x uint16 per table (entries past the table padded) for a SIMD symbol search.
+//   decoder: per table one cache-aligned record: (start | freq << 16) per value and a 128-entry
+//            first-guess table indexed by the top bits of the cumulative slot.  The guess is the value
+//            that owns the lower edge of the slot's bucket; a (well predicted, mostly zero-trip) loop
+//            walks up from there.  This keeps the state -> value -> state dependency chain at two L1
+//            loads, against ~17 cycles for a SIMD compare / movemask / popcount search.
 struct EncSym {
     uint32_t x_max, rcp_freq, bias;
     uint16_t cmpl_freq, rcp_shift;
+};
+
+constexpr int kLutBits = 7;
+struct alignas(64) DecTable {
+    uint32_t sym[36];                  // values 0..max_value (max_value = escape); rest unused
+    uint8_t lut[1 << kLutBits];
+    int16_t offset;
+    uint16_t max_value;
 };
 
 struct CdfGroup {
     int n = 0, stride = 0;
     std::vector<int32_t> cdf, sizes, offsets;
     std::vector<EncSym> esym;          // [n][stride]
-    std::vector<uint16_t> dcdf;        // [n][32]: cdf[1..], biased by 0x8000 for signed compares
-    std::vector<uint32_t> dmask;       // [n]: valid-lane mask (entries 1..max_value)
+    std::vector<DecTable> dtab;        // [n]
 };
 
 void build_fast_tables(CdfGroup& g)
 {
     g.esym.assign((size_t)g.n * g.stride, EncSym{0, 0, 0, 0, 0});
-    g.dcdf.assign((size_t)g.n * 32, 0x7fff);
-    g.dmask.assign(g.n, 0);
+    g.dtab.assign((size_t)g.n, DecTable{});
     for (int t = 0; t < g.n; ++t) {
         const int32_t* cdf = g.cdf.data() + (size_t)t * g.stride;
         const int nsym = g.sizes[t] - 1;                 // symbols 0..max_value (max_value = escape)
@@ -79,13 +89,16 @@ void build_fast_tables(CdfGroup& g)
                 e.bias = start;
             }
         }
-        const int max_value = g.sizes[t] - 2;
-        uint32_t mask = 0;
-        for (int i = 1; i <= max_value && i <= 32; ++i) {
-            g.dcdf[(size_t)t * 32 + (i - 1)] = (uint16_t)((uint32_t)cdf[i] ^ 0x8000u);
-            mask |= 1u << (i - 1);
+        DecTable& d = g.dtab[t];
+        d.offset = (int16_t)g.offsets[t];
+        d.max_value = (uint16_t)(nsym - 1);
+        for (int v = 0; v < nsym; ++v) d.sym[v] = (uint32_t)cdf[v] | ((uint32_t)(cdf[v + 1] - cdf[v]) << 16);
+        int v = 0;
+        for (int b = 0; b < (1 << kLutBits); ++b) {
+            const int32_t edge = b << (kScaleBits - kLutBits);
+            while (cdf[v + 1] <= edge) ++v;              // cdf[nsym] == 65536 > every edge
+            d.lut[b] = (uint8_t)v;
         }
-        g.dmask[t] = mask;
     }
 }
 
@@ -155,35 +168,104 @@ inline uint32_t kept_mask32_i16(const int16_t* p, int64_t n_left)
     return m;
 }
 
-// number of kept entries, the largest kept table index, and (if n0 >= 0) the position just after the
-// n0-th kept entry (= first position of the second coder)
-template <typename E, uint32_t (*MASK)(const E*, int64_t)>
-inline void scan_kept(const E* p, int64_t n, int64_t n0, int64_t& kept, int& max_idx, int64_t& split)
+// One pass over an index / packed-symbol array: kept entries per 32-entry chunk, their total and the
+// largest kept table index.  split_after(k) = the position just after the k-th kept entry (the first
+// position that belongs to the second coder when the first one takes k symbols).
+struct KeptScan {
+    std::vector<uint8_t> per_chunk;
+    int64_t kept = 0, n = 0;
+    int max_idx = 0;
+};
+
+inline void scan_kept_u8(const uint8_t* p, int64_t n, KeptScan& k)
 {
-    kept = 0;
-    max_idx = 0;
-    split = -1;
-    for (int64_t i = 0; i < n; i += 32) {
-        const uint32_t m = MASK(p + i, n - i);
-        const int c = __builtin_popcount(m);
-        if (split < 0 && n0 >= 0 && kept + c >= n0) {
-            int64_t need = n0 - kept;       // entries of this chunk that still belong to coder 0
-            uint32_t mm = m;
-            int pos = 0;
-            while (need > 0) {
-                pos = __builtin_ctz(mm) + 1;
-                mm &= mm - 1;
-                --need;
-            }
-            split = i + pos;
-        }
-        kept += c;
-        for (uint32_t mm = m; mm; mm &= mm - 1) {
-            const int v = (int)(p[i + __builtin_ctz(mm)] & 0xff);
-            max_idx = v > max_idx ? v : max_idx;
-        }
+    k.per_chunk.resize((size_t)((n + 31) / 32));
+    k.kept = 0;
+    k.n = n;
+    int64_t i = 0;
+    int mx = 0;
+#if defined(__AVX2__)
+    const __m256i ff = _mm256_set1_epi8((char)0xff);
+    __m256i vmax = _mm256_setzero_si256();
+    for (; i + 32 <= n; i += 32) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p + i));
+        const __m256i eq = _mm256_cmpeq_epi8(v, ff);
+        vmax = _mm256_max_epu8(vmax, _mm256_andnot_si256(eq, v));
+        const int c = __builtin_popcount(~(uint32_t)_mm256_movemask_epi8(eq));
+        k.per_chunk[(size_t)(i >> 5)] = (uint8_t)c;
+        k.kept += c;
     }
-    if (split < 0) split = n;
+    alignas(32) uint8_t lanes[32];
+    _mm256_store_si256(reinterpret_cast<__m256i*>(lanes), vmax);
+    for (int j = 0; j < 32; ++j) mx = lanes[j] > mx ? lanes[j] : mx;
+#endif
+    for (; i < n; i += 32) {
+        int c = 0;
+        for (int64_t j = i; j < n && j < i + 32; ++j)
+            if (p[j] != 0xff) {
+                ++c;
+                mx = p[j] > mx ? p[j] : mx;
+            }
+        k.per_chunk[(size_t)(i >> 5)] = (uint8_t)c;
+        k.kept += c;
+    }
+    k.max_idx = mx;
+}
+
+inline void scan_kept_i16(const int16_t* p, int64_t n, KeptScan& k)
+{
+    k.per_chunk.resize((size_t)((n + 31) / 32));
+    k.kept = 0;
+    k.n = n;
+    int64_t i = 0;
+    int mx = 0;
+#if defined(__AVX2__)
+    const __m256i lo = _mm256_set1_epi16(0x00ff);
+    __m256i vmax = _mm256_setzero_si256();
+    for (; i + 32 <= n; i += 32) {
+        const __m256i a = _mm256_and_si256(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(p + i)), lo);
+        const __m256i b = _mm256_and_si256(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(p + i + 16)), lo);
+        const __m256i ea = _mm256_cmpeq_epi16(a, lo), eb = _mm256_cmpeq_epi16(b, lo);
+        vmax = _mm256_max_epi16(vmax, _mm256_max_epi16(_mm256_andnot_si256(ea, a), _mm256_andnot_si256(eb, b)));
+        const uint32_t skipped = (uint32_t)_mm256_movemask_epi8(_mm256_packs_epi16(ea, eb));   // lane order irrelevant
+        const int c = 32 - __builtin_popcount(skipped);
+        k.per_chunk[(size_t)(i >> 5)] = (uint8_t)c;
+        k.kept += c;
+    }
+    alignas(32) int16_t lanes[16];
+    _mm256_store_si256(reinterpret_cast<__m256i*>(lanes), vmax);
+    for (int j = 0; j < 16; ++j) mx = lanes[j] > mx ? lanes[j] : mx;
+#endif
+    for (; i < n; i += 32) {
+        int c = 0;
+        for (int64_t j = i; j < n && j < i + 32; ++j) {
+            const int v = p[j] & 0xff;
+            if (v != 0xff) {
+                ++c;
+                mx = v > mx ? v : mx;
+            }
+        }
+        k.per_chunk[(size_t)(i >> 5)] = (uint8_t)c;
+        k.kept += c;
+    }
+    k.max_idx = mx;
+}
+
+template <typename E, uint32_t (*MASK)(const E*, int64_t)>
+inline int64_t split_after(const KeptScan& k, const E* p, int64_t take)
+{
+    if (take <= 0) return 0;
+    if (take >= k.kept) return k.n;
+    int64_t seen = 0;
+    size_t c = 0;
+    while (seen + k.per_chunk[c] < take) seen += k.per_chunk[c++];
+    uint32_t m = MASK(p + (int64_t)c * 32, k.n - (int64_t)c * 32);
+    int pos = 0;
+    for (int64_t need = take - seen; need > 0; --need) {
+        pos = __builtin_ctz(m) + 1;
+        m &= m - 1;
+    }
+    return (int64_t)c * 32 + pos;
 }
 
 // one background thread executing jobs in order
@@ -245,7 +327,8 @@ private:
 // ------------------------------------------------------------------ encoder half
 struct EncTask {
     bool is_z = false;
-    std::shared_ptr<std::vector<int16_t>> y;   // whole array incl. sentinels, shared by both halves
+    const int16_t* y = nullptr;                // whole array incl. sentinels, shared by both halves
+    std::shared_ptr<std::vector<int16_t>> y_own;   // set when the array was copied on entry
     int64_t begin = 0, end = 0;                // this half's range of y / z
     std::shared_ptr<std::vector<int8_t>> z;
     int group = 0, start_offset = 0, per_channel = 1;
@@ -265,13 +348,15 @@ inline void put_bits(uint32_t& r, uint8_t*& ptr, uint32_t val)
 inline void put_symbol(uint32_t& r, uint8_t*& ptr, const EncSym& e)
 {
     uint32_t x = r;
-    if (x >= e.x_max) {
+    // first renormalisation byte without a branch (taken for roughly every fourth symbol, i.e. badly
+    // predicted): always store below the write pointer, move the pointer only if the byte was needed
+    ptr[-1] = (uint8_t)(x & 0xff);
+    const bool spill = x >= e.x_max;
+    ptr -= spill;
+    x = spill ? x >> 8 : x;
+    if (__builtin_expect(x >= e.x_max, 0)) {
         *(--ptr) = (uint8_t)(x & 0xff);
         x >>= 8;
-        if (x >= e.x_max) {
-            *(--ptr) = (uint8_t)(x & 0xff);
-            x >>= 8;
-        }
     }
     const uint32_t q = (uint32_t)(((uint64_t)x * e.rcp_freq) >> 32) >> e.rcp_shift;
     r = x + e.bias + q * e.cmpl_freq;
@@ -321,11 +406,14 @@ struct EncHalf {
         for (auto it = tasks.rbegin(); it != tasks.rend(); ++it) {
             const CdfGroup& g = groups[it->group];
             if (it->is_z) {
-                const int8_t* z = it->z->data();
-                for (int64_t i = it->end - 1; i >= it->begin; --i)
-                    encode_symbol(r, ptr, z[i], g, (int)((i - it->begin) / it->per_channel) + it->start_offset);
+                const int8_t* z = it->z->data() + it->begin;
+                const int64_t len = it->end - it->begin;
+                int64_t i = len - 1;
+                for (int64_t ch = i / it->per_channel; i >= 0; --ch)       // channel by channel, backwards
+                    for (const int64_t first = ch * it->per_channel; i >= first; --i)
+                        encode_symbol(r, ptr, z[i], g, (int)ch + it->start_offset);
             } else {
-                const int16_t* y = it->y->data();
+                const int16_t* y = it->y;
                 // walk [begin, end) backwards in 32-entry chunks aligned to `begin`, visiting kept entries only
                 const int64_t len = it->end - it->begin;
                 for (int64_t c0 = ((len - 1) / 32) * 32; c0 >= 0 && len > 0; c0 -= 32) {
@@ -350,6 +438,67 @@ struct EncHalf {
 };
 
 // ------------------------------------------------------------------ decoder half
+// The coder state while a run of symbols is decoded: lives on the decoding thread's stack (so it
+// stays in registers; the int8 output stores could alias anything reachable through a pointer).
+struct DecCursor {
+    uint32_t x;
+    const uint8_t* cur;
+    const uint8_t* end;
+    bool overrun;
+
+    inline uint32_t next()
+    {
+        if (cur >= end) {
+            overrun = true;
+            return 0;
+        }
+        return *cur++;
+    }
+    inline uint32_t get_bits()
+    {
+        const uint32_t val = x & ((1u << kBypassBits) - 1);
+        x >>= kBypassBits;
+        if (x < kRansL) x = (x << 8) | next();
+        return val;
+    }
+    inline int32_t decode(const DecTable& t)
+    {
+        const uint32_t cum = x & kMask;
+        uint32_t s = t.lut[cum >> (kScaleBits - kLutBits)];
+        uint32_t e = t.sym[s];
+        uint32_t d = cum - (e & kMask);
+        while (d >= (e >> 16)) {              // cum lies past this value's range: walk up
+            e = t.sym[++s];
+            d = cum - (e & kMask);
+        }
+        x = (e >> 16) * (x >> kScaleBits) + d;
+        if (x < kRansL) {
+            x = (x << 8) | next();
+            if (x < kRansL) x = (x << 8) | next();
+        }
+        int32_t value = (int32_t)s;
+        if (s == t.max_value) {               // escape: Exp-Golomb-like bypass bits follow
+            int32_t val = (int32_t)get_bits();
+            int32_t n_bypass = val;
+            while (val == kBypassMax && !overrun) {
+                val = (int32_t)get_bits();
+                n_bypass += val;
+            }
+            int32_t raw = 0;
+            for (int j = 0; j < n_bypass && j < 16; ++j) {
+                val = (int32_t)get_bits();
+                raw |= val << (j * kBypassBits);
+            }
+            value = raw >> 1;
+            if (raw & 1)
+                value = -value - 1;
+            else
+                value += t.max_value;
+        }
+        return value + t.offset;
+    }
+};
+
 struct DecHalf {
     std::vector<uint8_t> buf;
     size_t pos = 0;
@@ -366,68 +515,42 @@ struct DecHalf {
         pos = 4;
         overrun = n < 4;
     }
-    inline uint8_t next()
+    DecCursor open() const { return DecCursor{state, buf.data() + pos, buf.data() + buf.size(), overrun}; }
+    void close(const DecCursor& c)
     {
-        if (pos >= buf.size()) {
-            overrun = true;
-            return 0;
-        }
-        return buf[pos++];
+        state = c.x;
+        pos = (size_t)(c.cur - buf.data());
+        overrun = c.overrun;
     }
-    inline uint32_t get_bits()
+
+    // y symbols of positions [a, b): zero-fill, then decode the kept entries (index != 0xFF) in order
+    void decode_range(const CdfGroup& g, const uint8_t* idx, int8_t* out, int64_t a, int64_t b)
     {
-        const uint32_t val = state & ((1u << kBypassBits) - 1);
-        state >>= kBypassBits;
-        if (state < kRansL) state = (state << 8) | next();
-        return val;
+        if (b <= a) return;
+        std::memset(out + a, 0, (size_t)(b - a));
+        const DecTable* tab = g.dtab.data();
+        DecCursor c = open();
+        for (int64_t c0 = a; c0 < b; c0 += 32) {
+            uint32_t m = kept_mask32_u8(idx + c0, b - c0);
+            while (m) {
+                const int bit = __builtin_ctz(m);
+                m &= m - 1;
+                out[c0 + bit] = (int8_t)c.decode(tab[idx[c0 + bit]]);
+            }
+        }
+        close(c);
     }
-    inline int8_t decode(const CdfGroup& g, int cdf_idx)
+
+    // z symbols: `cnt` values, `per_channel` consecutive ones share table start, start + 1, ...
+    void decode_channels(const CdfGroup& g, int8_t* out, int64_t cnt, int start, int per_channel)
     {
-        const int32_t* cdf = g.cdf.data() + (size_t)cdf_idx * g.stride;
-        const int32_t max_value = g.sizes[cdf_idx] - 2;
-        const uint32_t cum = state & kMask;
-        int s;
-#if defined(__AVX2__)
-        {   // s = #{ i in 1..max_value : cdf[i] <= cum }  (branch-free; tables have at most 33 entries)
-            const __m256i c = _mm256_set1_epi16((short)(cum ^ 0x8000u));
-            const __m256i* t = reinterpret_cast<const __m256i*>(g.dcdf.data() + (size_t)cdf_idx * 32);
-            const __m256i gt0 = _mm256_cmpgt_epi16(_mm256_loadu_si256(t), c);        // cdf[i] > cum
-            const __m256i gt1 = _mm256_cmpgt_epi16(_mm256_loadu_si256(t + 1), c);
-            const uint32_t m0 = (uint32_t)_mm256_movemask_epi8(_mm256_packs_epi16(gt0, gt1));
-            // packs interleaves 128-bit lanes: bits [0..7]=gt0.lo, [8..15]=gt1.lo, [16..23]=gt0.hi, [24..31]=gt1.hi
-            const uint32_t le = ~(((m0 & 0xffu)) | ((m0 >> 8) & 0xff00u) | ((m0 & 0xff00u) << 8) | (m0 & 0xff000000u));
-            s = __builtin_popcount(le & g.dmask[cdf_idx]);
+        const DecTable* tab = g.dtab.data() + start;
+        DecCursor c = open();
+        for (int64_t i = 0; i < cnt; ++tab) {
+            const int64_t stop = std::min<int64_t>(cnt, i + per_channel);
+            for (; i < stop; ++i) out[i] = (int8_t)c.decode(*tab);
         }
-#else
-        s = 0;
-        while (s < max_value && (uint32_t)cdf[s + 1] <= cum) ++s;
-#endif
-        const uint32_t start = (uint32_t)cdf[s], freq = (uint32_t)(cdf[s + 1] - cdf[s]);
-        state = freq * (state >> kScaleBits) + cum - start;
-        if (state < kRansL) {
-            state = (state << 8) | next();
-            if (state < kRansL) state = (state << 8) | next();
-        }
-        int32_t value = s;
-        if (value == max_value) {
-            int32_t val = (int32_t)get_bits();
-            int32_t n_bypass = val;
-            while (val == kBypassMax && !overrun) {
-                val = (int32_t)get_bits();
-                n_bypass += val;
-            }
-            int32_t raw = 0;
-            for (int j = 0; j < n_bypass && j < 16; ++j) {
-                val = (int32_t)get_bits();
-                raw |= val << (j * kBypassBits);
-            }
-            value = raw >> 1;
-            if (raw & 1)
-                value = -value - 1;
-            else
-                value += max_value;
-        }
-        return (int8_t)(value + g.offsets[cdf_idx]);
+        close(c);
     }
 };
 
@@ -439,6 +562,7 @@ struct dcvc_rans_enc {
     EncHalf half[2];
     Worker worker[2];
     std::vector<uint8_t> merged;
+    KeptScan scan;
     bool flushed = false;
 };
 
@@ -448,6 +572,8 @@ struct dcvc_rans_dec {
     DecHalf half[2];
     Worker worker[2];
     std::vector<int8_t> out;
+    std::vector<uint8_t> idx;      // copy of the indexes for the asynchronous decode_y
+    KeptScan scan;
 };
 
 extern "C" {
@@ -481,29 +607,26 @@ int dcvc_rans_enc_reset(dcvc_rans_enc* e)
     return 0;
 }
 
-int dcvc_rans_enc_encode_y(dcvc_rans_enc* e, const int16_t* symbols, int64_t n, int group)
+static int enc_add_y(dcvc_rans_enc* e, const int16_t* symbols, int64_t n, int group, bool copy, const char* who)
 {
-    DCVC_REQUIRE(e && (symbols || n == 0) && n >= 0, "dcvc_rans_enc_encode_y: bad arguments");
-    DCVC_REQUIRE(group >= 0 && group < (int)e->groups.size(), "dcvc_rans_enc_encode_y: unknown cdf group %d", group);
+    DCVC_REQUIRE(e && (symbols || n == 0) && n >= 0, "%s: bad arguments", who);
+    DCVC_REQUIRE(group >= 0 && group < (int)e->groups.size(), "%s: unknown cdf group %d", who, group);
     const CdfGroup& g = e->groups[group];
-    auto buf = std::make_shared<std::vector<int16_t>>(symbols, symbols + n);   // inputs are copied on entry
-    const int16_t* y = buf->data();
-    int64_t kept = 0, split = n;   // split: first position that belongs to coder 1
-    int max_idx = 0;
-    scan_kept<int16_t, kept_mask32_i16>(y, n, -1, kept, max_idx, split);
-    DCVC_REQUIRE(max_idx < g.n, "dcvc_rans_enc_encode_y: cdf index %d out of range (%d tables)", max_idx, g.n);
-    const int64_t n0 = e->two ? kept / 2 : kept;
-    if (e->two) {
-        int64_t k2;
-        int mx2;
-        scan_kept<int16_t, kept_mask32_i16>(y, n, n0, k2, mx2, split);
-        if (n0 == 0) split = 0;
-    } else {
-        split = n;
+    std::shared_ptr<std::vector<int16_t>> own;
+    const int16_t* y = symbols;
+    if (copy) {
+        own = std::make_shared<std::vector<int16_t>>(symbols, symbols + n);
+        y = own->data();
     }
+    scan_kept_i16(y, n, e->scan);
+    DCVC_REQUIRE(e->scan.max_idx < g.n, "%s: cdf index %d out of range (%d tables)", who, e->scan.max_idx, g.n);
+    const int64_t kept = e->scan.kept;
+    const int64_t n0 = e->two ? kept / 2 : kept;
+    const int64_t split = e->two ? split_after<int16_t, kept_mask32_i16>(e->scan, y, n0) : n;
     EncTask t0;
     t0.group = group;
-    t0.y = buf;
+    t0.y = y;
+    t0.y_own = own;
     t0.begin = 0;
     t0.end = split;
     t0.count = n0;
@@ -511,13 +634,24 @@ int dcvc_rans_enc_encode_y(dcvc_rans_enc* e, const int16_t* symbols, int64_t n, 
     if (e->two) {
         EncTask t1;
         t1.group = group;
-        t1.y = buf;
+        t1.y = y;
+        t1.y_own = own;
         t1.begin = split;
         t1.end = n;
         t1.count = kept - n0;
         e->half[1].tasks.push_back(std::move(t1));
     }
     return 0;
+}
+
+int dcvc_rans_enc_encode_y(dcvc_rans_enc* e, const int16_t* symbols, int64_t n, int group)
+{
+    return enc_add_y(e, symbols, n, group, true, "dcvc_rans_enc_encode_y");
+}
+
+int dcvc_rans_enc_encode_y_borrowed(dcvc_rans_enc* e, const int16_t* symbols, int64_t n, int group)
+{
+    return enc_add_y(e, symbols, n, group, false, "dcvc_rans_enc_encode_y_borrowed");
 }
 
 int dcvc_rans_enc_encode_z(dcvc_rans_enc* e, const int8_t* symbols, int64_t n, int group, int start_offset,
@@ -622,44 +756,47 @@ int dcvc_rans_dec_set_stream(dcvc_rans_dec* d, const uint8_t* data, int64_t n)
     return 0;
 }
 
+// common part of the two y entry points: scan, split, run coder 1 on its worker and coder 0 either
+// on its worker (asynchronous form) or on the calling thread (synchronous form)
+static int dec_run_y(dcvc_rans_dec* d, const uint8_t* ip, int64_t n, int group, int8_t* out, bool inline0,
+                     const char* who)
+{
+    DCVC_REQUIRE(group >= 0 && group < (int)d->groups.size(), "%s: unknown cdf group %d", who, group);
+    const CdfGroup* g = &d->groups[group];
+    scan_kept_u8(ip, n, d->scan);
+    DCVC_REQUIRE(d->scan.max_idx < g->n, "%s: cdf index %d out of range (%d tables)", who, d->scan.max_idx, g->n);
+    const int64_t split = d->two ? split_after<uint8_t, kept_mask32_u8>(d->scan, ip, d->scan.kept / 2) : n;
+    if (d->two) d->worker[1].post([=] { d->half[1].decode_range(*g, ip, out, split, n); });
+    if (inline0)
+        d->half[0].decode_range(*g, ip, out, 0, split);
+    else
+        d->worker[0].post([=] { d->half[0].decode_range(*g, ip, out, 0, split); });
+    return 0;
+}
+
 int dcvc_rans_dec_decode_y(dcvc_rans_dec* d, const uint8_t* indexes, int64_t n, int group)
 {
     DCVC_REQUIRE(d && (indexes || n == 0) && n >= 0, "dcvc_rans_dec_decode_y: bad arguments");
-    DCVC_REQUIRE(group >= 0 && group < (int)d->groups.size(), "dcvc_rans_dec_decode_y: unknown cdf group %d", group);
     d->worker[0].wait_idle();
     d->worker[1].wait_idle();
-    auto idx = std::make_shared<std::vector<uint8_t>>(indexes, indexes + n);
-    const CdfGroup* g = &d->groups[group];
-    const uint8_t* ip = idx->data();
-    int64_t kept = 0, split = n;   // split: first position handled by coder 1
-    int max_idx = 0;
-    scan_kept<uint8_t, kept_mask32_u8>(ip, n, -1, kept, max_idx, split);
-    DCVC_REQUIRE(max_idx < g->n, "dcvc_rans_dec_decode_y: cdf index %d out of range (%d tables)", max_idx, g->n);
-    d->out.assign((size_t)n, 0);
-    if (d->two) {
-        int64_t k2;
-        int mx2;
-        scan_kept<uint8_t, kept_mask32_u8>(ip, n, kept / 2, k2, mx2, split);
-        if (kept / 2 == 0) split = 0;
-    } else {
-        split = n;
+    d->idx.assign(indexes, indexes + n);          // inputs are copied on entry
+    d->out.resize((size_t)n);
+    return dec_run_y(d, d->idx.data(), n, group, d->out.data(), false, "dcvc_rans_dec_decode_y");
+}
+
+int dcvc_rans_dec_decode_and_get_y(dcvc_rans_dec* d, const uint8_t* indexes, int64_t n, int group, int8_t* out)
+{
+    DCVC_REQUIRE(d && ((indexes && out) || n == 0) && n >= 0, "dcvc_rans_dec_decode_and_get_y: bad arguments");
+    d->worker[0].wait_idle();
+    d->worker[1].wait_idle();
+    d->out.clear();
+    const int rc = dec_run_y(d, indexes, n, group, out, true, "dcvc_rans_dec_decode_and_get_y");
+    if (rc) return rc;
+    d->worker[1].wait_idle();
+    if (d->half[0].overrun || (d->two && d->half[1].overrun)) {
+        dcvc::set_error("dcvc_rans_dec_decode_and_get_y: bit stream exhausted (corrupt or truncated stream)");
+        return dcvc::E_STREAM;
     }
-    int8_t* out = d->out.data();
-    auto job = [idx, g, out](DecHalf* h, int64_t a, int64_t b) {
-        const uint8_t* q = idx->data();
-        DecHalf local = std::move(*h);          // keep the coder state on this thread's stack
-        for (int64_t c0 = a; c0 < b; c0 += 32) {   // visit kept entries only
-            uint32_t m = kept_mask32_u8(q + c0, b - c0);
-            while (m) {
-                const int bit = __builtin_ctz(m);
-                m &= m - 1;
-                out[c0 + bit] = local.decode(*g, q[c0 + bit]);
-            }
-        }
-        *h = std::move(local);
-    };
-    d->worker[0].post([=] { job(&d->half[0], 0, split); });
-    if (d->two) d->worker[1].post([=] { job(&d->half[1], split, n); });
     return 0;
 }
 
@@ -675,13 +812,10 @@ int dcvc_rans_dec_decode_z(dcvc_rans_dec* d, int64_t total, int group, int start
     d->out.assign((size_t)total, 0);
     int8_t* out = d->out.data();
     const int64_t n0 = d->two ? total / 2 : total;
-    auto job = [g, out, per_channel_size](DecHalf* h, int64_t base, int64_t cnt, int start) {
-        for (int64_t i = 0; i < cnt; ++i) out[base + i] = h->decode(*g, (int)(i / per_channel_size) + start);
-    };
-    d->worker[0].post([=] { job(&d->half[0], 0, n0, start_offset); });
+    d->worker[0].post([=] { d->half[0].decode_channels(*g, out, n0, start_offset, per_channel_size); });
     if (d->two) {
         const int start1 = start_offset + (int)(n0 / per_channel_size);
-        d->worker[1].post([=] { job(&d->half[1], n0, total - n0, start1); });
+        d->worker[1].post([=] { d->half[1].decode_channels(*g, out + n0, total - n0, start1, per_channel_size); });
     }
     return 0;
 }

@@ -157,10 +157,12 @@ class EntropyCoder:
     def reset(self):
         check(_lib.lib().dcvc_rans_enc_reset(self.enc), "rans reset")
 
-    def encode_y(self, symbols, cdf_group_index):
-        """symbols: host int16 array ((sym << 8) + index, index 0xFF = skipped)."""
+    def encode_y(self, symbols, cdf_group_index, borrowed=False):
+        """symbols: host int16 array ((sym << 8) + index, index 0xFF = skipped).  borrowed=True skips the
+        copy: the array must then stay untouched until get_encoded_stream() has returned."""
         symbols = np.ascontiguousarray(symbols, np.int16)
-        check(_lib.lib().dcvc_rans_enc_encode_y(self.enc, _ip(symbols), symbols.size, cdf_group_index), "encode_y")
+        f = _lib.lib().dcvc_rans_enc_encode_y_borrowed if borrowed else _lib.lib().dcvc_rans_enc_encode_y
+        check(f(self.enc, _ip(symbols), symbols.size, cdf_group_index), "encode_y")
 
     def encode_z(self, symbols, cdf_group_index, start_offset, per_channel_size):
         symbols = np.ascontiguousarray(symbols, np.int8)
@@ -194,5 +196,10 @@ class EntropyCoder:
         return n
 
     def decode_and_get_y(self, indexes, cdf_group_index, out):
-        self.decode_y(indexes, cdf_group_index)
-        return self.get_decoded(out)
+        """Synchronous: decodes straight from `indexes` into `out` (both host arrays of the same length)."""
+        if indexes.dtype != np.uint8 or out.dtype != np.int8 or out.size < indexes.size or \
+                not indexes.flags.c_contiguous or not out.flags.c_contiguous:
+            raise DcvcError("decode_and_get_y: need contiguous uint8 indexes and an int8 output of the same length")
+        check(_lib.lib().dcvc_rans_dec_decode_and_get_y(self.dec, _ip(indexes), indexes.size, cdf_group_index,
+                                                        _ip(out)), "decode_and_get_y")
+        return indexes.size

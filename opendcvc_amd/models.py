@@ -385,8 +385,8 @@ class DMC(CompressionModel):
         zh, zw = z.shape[0], z.shape[1]
         ec.encode_z(hz.view(np.int8, z8.numel()), self._z_group, qp * self.z_channel, zh * zw)
         ps = hp.view(np.int16, 2 * nsym)
-        ec.encode_y(ps[:nsym], self._g_group)
-        ec.encode_y(ps[nsym:], self._g_group)
+        ec.encode_y(ps[:nsym], self._g_group, borrowed=True)     # pinned staging buffer, untouched until
+        ec.encode_y(ps[nsym:], self._g_group, borrowed=True)     # get_encoded_stream() below
         ec.flush()
         bit_stream = ec.get_encoded_stream()
 
@@ -520,7 +520,7 @@ class DMCI(CompressionModel):
         ec.encode_z(hz.view(np.int8, z8.numel()), self._z_group, qp * self.z_channel, z.shape[0] * z.shape[1])
         ps = hp.view(np.int16, 4 * nsym)
         for k in range(4):
-            ec.encode_y(ps[k * nsym:(k + 1) * nsym], self._g_group)
+            ec.encode_y(ps[k * nsym:(k + 1) * nsym], self._g_group, borrowed=True)
         ec.flush()
         bit_stream = ec.get_encoded_stream()
         torch.cuda.synchronize(device=device)
