@@ -4,9 +4,13 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One step = one frame of a 32-frame-GOP 1080p sequence (configs[1]) ENCODED and then DECODED by the
-HIP path (fp16 storage / fp32 accumulate, like the reference's published numbers), including the
-host rANS coding, with the padded input frames already resident in HBM.  With N > 1 every rank
+One step = one frame of a 32-frame-GOP 1080p sequence (configs[1]) ENCODED and DECODED by the HIP
+path (fp16 storage / fp32 accumulate, like the reference's published numbers), including the host
+rANS coding, with the padded input frames already resident in HBM.  The timed region runs the
+encoder and the decoder as a two-stage pipeline (two host threads, two HIP streams on the same GPU:
+frame n decodes while frame n+1 encodes); after it, the same frames are run one direction at a time
+for the per-direction fps (`enc_fps_per_gpu`, `dec_fps_per_gpu`, `sequential_*`), which is how the
+reference times them and what `vs_baseline` compares.  With N > 1 every rank
 codes its own independent stream (weak scaling, no data-path collective; the weights are
 broadcast once from rank 0 over RCCL).  Rank 0 prints ONE JSON line.
 
@@ -33,7 +37,7 @@ from opendcvc_amd import _lib, weights  # noqa: E402
 from opendcvc_amd import dist as dist_utils  # noqa: E402
 from opendcvc_amd import nn as L  # noqa: E402
 from opendcvc_amd.models import DMC, DMCI  # noqa: E402
-from opendcvc_amd.pipeline import SequenceDecoder, SequenceEncoder, use_two_entropy_coders  # noqa: E402
+from opendcvc_amd.pipeline import EncodeDecodePipeline, SequenceDecoder, SequenceEncoder, use_two_entropy_coders  # noqa: E402
 
 HEIGHT, WIDTH = 1080, 1920
 GOP = 32
@@ -156,54 +160,85 @@ def main():
     enc = SequenceEncoder(ie, pe, QP, intra_period=GOP, reset_interval=GOP)
     dec = SequenceDecoder(idec, pdec, HEIGHT, WIDTH, two)
 
-    state = {"i": 0, "t_enc": 0.0, "t_dec": 0.0, "bytes": 0, "n_i": 0}
+    state = {"i": 0, "t_enc": 0.0, "t_dec": 0.0, "bytes": 0, "n_i": 0, "j": 0}
 
-    def step(timed):
+    def step_sequential():
+        """encode, wait, decode, wait - used for the per-direction fps (how the reference times them)"""
         x = frames[state["i"] % GOP]
         state["i"] += 1
         t0 = time.perf_counter()
-        pkt = enc.encode(x)
+        with torch.cuda.stream(s_enc):
+            pkt = enc.encode(x)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        x_hat = dec.decode(pkt)
+        with torch.cuda.stream(s_dec):
+            dec.decode(pkt)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        if timed:
-            state["t_enc"] += t1 - t0
-            state["t_dec"] += t2 - t1
-            state["bytes"] += len(pkt.bit_stream)
-            state["n_i"] += int(pkt.is_i)
-        return x_hat
+        state["t_enc"] += t1 - t0
+        state["t_dec"] += t2 - t1
+
+    pipe = EncodeDecodePipeline(enc, dec, device)
+    s_enc, s_dec = pipe.enc_stream, pipe.dec_stream
+
+    def run_pipelined(nsteps, timed):
+        """nsteps frames through encoder AND decoder (opendcvc_amd/pipeline.py: two host threads, two HIP
+        streams; frame n decodes while frame n+1 encodes).  Every frame is fully encoded and fully
+        decoded inside the call."""
+        first = state["i"]
+        state["i"] += nsteps
+
+        def on_packet(pkt):
+            if timed:
+                state["bytes"] += len(pkt.bit_stream)
+                state["n_i"] += int(pkt.is_i)
+
+        def on_frame(_):
+            state["j"] += 1
+
+        pipe.run((frames[k % GOP] for k in range(first, first + nsteps)), on_packet, on_frame)
 
     def barrier():
         dist_utils.barrier(world)
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
+    torch.cuda.synchronize()
+    run_pipelined(args.warmup, False)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    run_pipelined(args.steps, True)
     barrier()
     elapsed = dist_utils.max_over_ranks(time.perf_counter() - t0, device, world)
+    assert state["j"] == args.warmup + args.steps
+
+    # outside the timed region: the same frames one direction at a time
+    n_seq = min(args.steps, GOP)
+    t_seq0 = time.perf_counter()
+    for _ in range(n_seq):
+        step_sequential()
+    t_seq = time.perf_counter() - t_seq0
 
     if rank == 0:
         K, N = args.steps, world
         value = N * K / elapsed
+        seq_value = n_seq / t_seq                   # this rank, encode then decode one after the other
         base = 1.0 / (1.0 / BASELINE_ENC_FPS + 1.0 / BASELINE_DEC_FPS)
         out = {
             "metric": "1080p YUV420 encode+decode FPS (frames/s through encode AND decode, whole job)",
             "value": round(value, 3), "unit": "frames/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": round(value / N / base, 4), "dtype": "f16", "data": "synthetic",
+            "vs_baseline": round(seq_value / base, 4), "dtype": "f16", "data": "synthetic",
             "config": {"workload": "DCVC-RT inter-coding, 1080p YUV420 32-frame GOP, single q (qp 32), "
                                    "one stream per MI355X (BASELINE.json configs[1])",
                        "frame": "1920x1080 padded to 1920x1088", "intra_period": GOP, "i_frames_timed": state["n_i"],
                        "entropy_coders": 2 if two else 1, "force_zero_thres": THRES,
                        "weights": "synthetic seed 1234 (opendcvc_amd/weights.py)",
-                       "baseline_note": "vs_baseline = per-GPU value / (1/(1/125.2+1/112.8)) fps, reference README A100 fp16"},
-            "enc_fps_per_gpu": round(K / state["t_enc"], 2), "dec_fps_per_gpu": round(K / state["t_dec"], 2),
+                       "pipeline": "encoder and decoder on two host threads / two HIP streams of the same GPU: frame n "
+                                   "decodes while frame n+1 encodes; every timed frame is encoded and decoded",
+                       "baseline_note": "vs_baseline = sequential_fps_per_gpu / (1/(1/125.2+1/112.8)) fps (reference README, "
+                                        "A100 fp16, encode and decode timed one after the other as in the reference)"},
+            "sequential_fps_per_gpu": round(seq_value, 3), "sequential_ms_per_step": round(1e3 * t_seq / n_seq, 3),
+            "enc_fps_per_gpu": round(n_seq / state["t_enc"], 2), "dec_fps_per_gpu": round(n_seq / state["t_dec"], 2),
             "bpp": round(state["bytes"] * 8.0 / (K * HEIGHT * WIDTH), 5),
         }
         out["roofline"] = roofline_leg(pe, device, dtype)

@@ -389,8 +389,8 @@ class DMC(CompressionModel):
         ec.encode_y(ps[nsym:], self._g_group, borrowed=True)     # get_encoded_stream() below
         ec.flush()
         bit_stream = ec.get_encoded_stream()
-
-        torch.cuda.synchronize(device=device)
+        # no device synchronisation here (the reference has none either): the tail of the decoder stays in
+        # flight on this stream and overlaps the caller's next host work; callers that time a frame sync.
         self.add_ref_frame(feature, None)
         return {"bit_stream": bit_stream}
 
@@ -523,7 +523,6 @@ class DMCI(CompressionModel):
             ec.encode_y(ps[k * nsym:(k + 1) * nsym], self._g_group, borrowed=True)
         ec.flush()
         bit_stream = ec.get_encoded_stream()
-        torch.cuda.synchronize(device=device)
         return {"bit_stream": bit_stream, "x_hat": x_hat}
 
     def decompress(self, bit_stream, sps, qp):

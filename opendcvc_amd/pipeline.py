@@ -64,6 +64,69 @@ class SequenceDecoder:
         return dec["x_hat"]
 
 
+class EncodeDecodePipeline:
+    """Encoder and decoder of one stream as a two-stage pipeline on one GPU: each stage has its own host
+    thread and HIP stream, so frame n is decoded while frame n+1 is encoded and one stage's host entropy
+    coding overlaps the other stage's kernels.  (The reference runs the two loops one after the other,
+    test_video.py:164-214 then :258-285; the frames, packets and reconstructions are the same.)"""
+
+    def __init__(self, encoder, decoder, device, depth=2):
+        import torch
+        self.encoder, self.decoder, self.device, self.depth = encoder, decoder, device, depth
+        self.enc_stream, self.dec_stream = torch.cuda.Stream(device), torch.cuda.Stream(device)
+
+    def run(self, frames, on_packet=None, on_frame=None):
+        """frames: iterable of padded model inputs (device tensors, ready on the calling stream).
+        on_packet(pkt) is called on the encoder thread, on_frame(x_hat) on the decoder thread with the
+        decoder stream current.  Returns when every frame has been encoded and decoded."""
+        import queue
+        import threading
+        import torch
+        torch.cuda.current_stream().synchronize()
+        q = queue.Queue(maxsize=self.depth)
+        errors = []
+
+        def enc_stage():
+            try:
+                torch.cuda.set_device(self.device)
+                with torch.cuda.stream(self.enc_stream):
+                    for x in frames:
+                        pkt = self.encoder.encode(x)
+                        if on_packet is not None:
+                            on_packet(pkt)
+                        q.put(pkt)
+                    self.enc_stream.synchronize()
+            except BaseException as e:                      # re-raised by run()
+                errors.append(e)
+            finally:
+                q.put(None)
+
+        def dec_stage():
+            try:
+                torch.cuda.set_device(self.device)
+                with torch.cuda.stream(self.dec_stream):
+                    while True:
+                        pkt = q.get()
+                        if pkt is None:
+                            break
+                        x_hat = self.decoder.decode(pkt)
+                        if on_frame is not None:
+                            on_frame(x_hat)
+                    self.dec_stream.synchronize()
+            except BaseException as e:
+                errors.append(e)
+                while q.get() is not None:                  # keep the encoder from blocking on a full queue
+                    pass
+
+        threads = [threading.Thread(target=enc_stage), threading.Thread(target=dec_stage)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+
+
 def load_yuv420_frame(y, u, v, dtype, pad_to=16):
     """uint8 CUDA planes y [H,W], u/v [H/2,W/2] -> padded model input [1,3,H',W'] (one fused kernel;
     reference: get_src_frame + replicate_pad, test_video.py:74-91,150,179)."""

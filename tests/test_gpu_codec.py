@@ -89,3 +89,34 @@ def test_requires_update_and_cuda():
     m.to("cuda")
     with pytest.raises(DcvcError):
         m.compress(torch.zeros(1, 3, 64, 64, device="cuda"), 0)   # update() not called
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_two_stage_pipeline_equals_sequential(dtype):
+    """EncodeDecodePipeline (encoder / decoder on two host threads and HIP streams) = the plain
+    encode-then-decode loop: same packets, same reconstructions, frame for frame."""
+    from opendcvc_amd.pipeline import EncodeDecodePipeline, SequenceDecoder, SequenceEncoder
+    h, w, n = 144, 256, 7
+    frames = [torch.from_numpy(weights.synthetic_frame_yuv444(h, w, fi, 3)).to("cuda", dtype) for fi in range(n)]
+
+    def codecs():
+        (ie, pe), (idc, pdc) = hip_codecs(1234, 0.12, dtype), hip_codecs(1234, 0.12, dtype)
+        for m in (ie, pe, idc, pdc):
+            m.set_use_two_entropy_coders(True)
+        return (SequenceEncoder(ie, pe, 20, intra_period=4, reset_interval=3),
+                SequenceDecoder(idc, pdc, h, w, True))
+
+    enc, dec = codecs()
+    want = []
+    for x in frames:
+        pkt = enc.encode(x)
+        want.append((pkt, dec.decode(pkt).float().cpu().numpy()))
+    enc, dec = codecs()
+    pkts, outs = [], []
+    EncodeDecodePipeline(enc, dec, torch.device("cuda", 0)).run(
+        frames, on_packet=pkts.append, on_frame=lambda t: outs.append(t.float().cpu().numpy()))
+    assert len(pkts) == len(outs) == n
+    for fi, ((wp, wx), gp, gx) in enumerate(zip(want, pkts, outs)):
+        assert (gp.is_i, gp.qp, gp.use_ada_i) == (wp.is_i, wp.qp, wp.use_ada_i)
+        assert gp.bit_stream == wp.bit_stream, f"frame {fi}: packet differs"
+        assert np.array_equal(gx, wx), f"frame {fi}: reconstruction differs"

@@ -130,3 +130,73 @@ def test_errors_are_reported():
         c.set_stream(b"\x00")                          # too short
     with pytest.raises(_lib.DcvcError):
         c.get_encoded_stream()                         # flush() not called
+
+
+@pytest.mark.parametrize("two", [0, 1])
+def test_entry_point_variants_agree(kat, two):
+    """borrowed-buffer encode == copying encode; asynchronous decode_y + get == decode_and_get_y."""
+    c = coder(kat, two)
+    p = packed_of(kat)
+    c.reset()
+    c.encode_z(kat["z"], 0, 0, 6)
+    c.encode_y(p, 0, borrowed=True)
+    c.encode_y(p[:777], 0, borrowed=True)
+    c.encode_y(p[:0], 0, borrowed=True)
+    c.flush()
+    s = c.get_encoded_stream()
+    assert s == kat[f"stream_two{two}"].tobytes()
+    c.set_stream(s)
+    z = np.empty(kat["z"].size, np.int8)
+    c.decode_z(z.size, 0, 0, 6)
+    c.get_decoded(z)
+    y = np.empty(kat["idx"].size, np.int8)
+    c.decode_y(kat["idx"], 0)
+    c.get_decoded(y)
+    assert np.array_equal(y, kat["sym"].astype(np.int8))
+    y2 = np.empty(777, np.int8)
+    c.decode_and_get_y(np.ascontiguousarray(kat["idx"][:777]), 0, y2)
+    assert np.array_equal(y2, kat["sym"][:777].astype(np.int8))
+    with pytest.raises(_lib.DcvcError):
+        c.decode_and_get_y(kat["idx"], 0, np.empty(3, np.int8))       # output too small
+
+
+def test_real_1080p_frame_inputs(golden_dir):
+    """The coder inputs of one 1080p P frame recorded on the MI355X box (tools/dump_coder_inputs.py):
+    same stream as the oracle coder (itself pinned to the reference), and it decodes back."""
+    from opendcvc_amd import entropy, weights
+    d = np.load(os.path.join(golden_dir, "coder_inputs_1080p.npz"))
+    sd = weights.make_state_dict("dmc", 1234)
+    pre = "bit_estimator_z."
+    params = {k[len(pre):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith(pre)}
+    ztab = entropy.factorized_cdf_tables(params, 72, 128)
+    c = entropy.EntropyCoder()
+    o = O.Coder()
+    for t in (entropy.gaussian_cdf_tables(), ztab):
+        c.add_cdf(*t)
+        o.add_cdf(*t)
+    c.set_use_two_entropy_coders(True)
+    o.set_use_two(1)
+    zg, zoff, zper = (int(v) for v in d["z_args"])
+    yg = int(d["y_group"])
+    c.reset()
+    o.reset()
+    c.encode_z(d["z"], zg, zoff, zper)
+    o.encode_z(d["z"], zg, zoff, zper)
+    packed = [d["packed0"], d["packed1"]]          # borrowed: must outlive get_encoded_stream()
+    for p in packed:
+        c.encode_y(p, yg, borrowed=True)
+        o.encode_y(p[(p & 0xff) != 0xff], yg)
+    c.flush()
+    s = c.get_encoded_stream()
+    assert s == d["stream"].tobytes() == o.flush()
+    c.set_stream(s)
+    z = np.empty(d["z"].size, np.int8)
+    c.decode_z(z.size, zg, zoff, zper)
+    c.get_decoded(z)
+    assert np.array_equal(z, d["z"])
+    for k in ("0", "1"):
+        p, idx = d["packed" + k], d["index" + k]
+        out = np.empty(idx.size, np.int8)
+        c.decode_and_get_y(idx, yg, out)
+        kept = idx != 0xff
+        assert np.array_equal(out[kept], (p >> 8)[kept].astype(np.int8)) and not out[~kept].any()
