@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <functional>
 #include <memory>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "common.hpp"
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(NTHREADS) void dcb_head_kernel(HeadParams p)
         for (int m = 0; m < MT; ++m) {
             floatx4 v = acc[m][i] + bias;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = TR::wsilu(v[r]);
+            for (int r = 0; r < 4; ++r) v[r] = TR::gate(v[r]);   // fp16 mode: kAct * wsilu, undone by the depthwise taps
             lds_store_quad<T>(bufX, ldx, m * 16 + pl, ch0, v);
         }
     }
@@ -181,6 +183,11 @@ struct TailParams {
     unsigned long long* stamps;   // diagnostic build only (DCVC_STAMPS): 8 cycle counters per workgroup
 };
 
+// Diagnostics (phase stamps, phase ablation) exist only in a -DDCVC_DIAG build (make diag): in the
+// production kernel even a never-taken branch around a GEMM makes hipcc keep two copies of the
+// accumulators and shuffle 64 registers per FFN chunk.
+#ifdef DCVC_DIAG
+#define ABLATED(bit) ((p.ablate & (bit)) != 0)
 #define STAMP(var)                                                   \
     do {                                                             \
         if (p.stamps) {                                              \
@@ -189,6 +196,12 @@ struct TailParams {
             __builtin_amdgcn_sched_barrier(0);                       \
         }                                                            \
     } while (0)
+#else
+#define ABLATED(bit) false
+#define STAMP(var) \
+    do {           \
+    } while (0)
+#endif
 
 // channels per depthwise slab staged in LDS (with its 1-pixel halo): 128 in fp16 (widths that are
 // multiples of 128), else 64
@@ -199,7 +212,7 @@ template <int MT, int NTW, int NW>
 struct TailCfg {   // small blocks run two workgroups per CU: shallower prefetch, narrower FFN chunk.
                    // NW = waves per workgroup (4, or 8: more waves per SIMD hide latency by switching waves)
     static constexpr bool two_per_cu = (MT <= 4 && NTW * NW <= 16);
-    static constexpr int NTV = two_per_cu ? 1 : 2;
+    static constexpr int NTV = (two_per_cu || NW == 8) ? 1 : 2;
     static constexpr int waves_per_simd = (two_per_cu ? 2 : 1) * NW / 4;
 };
 
@@ -215,7 +228,9 @@ struct TailLds {
     static size_t bytes(int C) { return ((size_t)M * (C + TR::kPad) + v_elems) * sizeof(T); }
 };
 
-template <typename T, int MT, int NTW, int NW>
+// RAG ("ragged"): the width is 4 channel tiles short of NTW * NW * 16 (C = 320 on 8 waves x 3 tiles): the
+// waves whose last tile does not exist run it on a clamped weight tile and drop the result.
+template <typename T, int MT, int NTW, int NW, bool RAG = false>
 __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) void dcb_tail_kernel(TailParams p)
 {
     using TR = Traits<T>;
@@ -241,19 +256,23 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
     const T* a = reinterpret_cast<const T*>(p.a);
     const T* ident = reinterpret_cast<const T*>(p.ident);
     const int GC = C / V;
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tg3 = 0, tep = 0, tg4 = 0, tt = 0, tt2 = 0;
+    [[maybe_unused]] unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tg3 = 0, tep = 0, tg4 = 0, tt = 0, tt2 = 0;
     STAMP(ts0);
     const int pl = lane & 15, cq = (lane >> 4) * 4;
-    int tiles[NTW];
+    int tiles[NTW], wtiles[NTW];   // output tiles of this wave; wtiles = the same, clamped to existing weight tiles
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) tiles[i] = wave + NW * i;
+    for (int i = 0; i < NTW; ++i) {
+        tiles[i] = wave + NW * i;
+        wtiles[i] = RAG ? min(tiles[i], C / 16 - 1) : tiles[i];
+    }
+    auto tile_exists = [&](int i) { return !RAG || tiles[i] < C / 16; };
     WPre<T, NTW, PF> pre2;   // W2's first groups are requested now and land during the depthwise stage
-    gemm_prefetch<T, NTW, PF>(pre2, C / KG, reinterpret_cast<const frag_t*>(p.w2), C / KG, 0, tiles, lane);
+    gemm_prefetch<T, NTW, PF>(pre2, C / KG, reinterpret_cast<const frag_t*>(p.w2), C / KG, 0, wtiles, lane);
 
     {   // depthwise 3x3 (zero padding), taps in (ky,kx) order, + bias.  The activation tile and its
         // 1-pixel halo go through LDS one 64-channel slab at a time (each input element is fetched
         // from L2 1.4-1.6x instead of 9x); the next slab is prefetched into registers meanwhile.
-        constexpr int DW_SLAB = (dw_slab_max<T>() == 128 && (NTW * NW) % 8 == 0) ? 128 : 64;
+        constexpr int DW_SLAB = (!RAG && dw_slab_max<T>() == 128 && (NTW * NW) % 8 == 0) ? 128 : 64;
         constexpr int HW_ = TW + 2, HALO = LD::HALO, GS = DW_SLAB / V, lds_s = LD::lds_slab;
         constexpr int NLD = (HALO * GS + NTHREADS_ - 1) / NTHREADS_;
         const T* wd = reinterpret_cast<const T*>(p.wd);
@@ -267,7 +286,7 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
                 if (it < HALO * GS) {
                     const int hp = it / GS, c = slab * DW_SLAB + (it - hp * GS) * V;
                     const int y = ty0 - 1 + hp / HW_, x = tx0 - 1 + hp % HW_;
-                    if (y >= 0 && y < p.H && x >= 0 && x < p.W && !(p.ablate & 1))
+                    if (y >= 0 && y < p.H && x >= 0 && x < p.W && !ABLATED(1))
                         v = *reinterpret_cast<const Vec16*>(a + ((long)y * p.W + x) * p.lda + c);
                 }
                 pre[k] = v;
@@ -337,8 +356,8 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
 
     floatx4 acc[MT][NTW];
     zero_acc(acc);
-    if (!(p.ablate & 2))
-        gemm_run<T, MT, NTW, PF>(acc, bufX, ldx, C / KG, pre2, reinterpret_cast<const frag_t*>(p.w2), C / KG, 0, tiles, lane);
+    if (!ABLATED(2))
+        gemm_run<T, MT, NTW, PF>(acc, bufX, ldx, C / KG, pre2, reinterpret_cast<const frag_t*>(p.w2), C / KG, 0, wtiles, lane);
     const int vtiles = 2 * C / 16;
     int ut[2 * NTV];
 #pragma unroll
@@ -353,9 +372,11 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         const int ch0 = tiles[i] * 16 + cq;
-        const floatx4 bias = load_f4(p.b2 + ch0);
+        const floatx4 bias = load_f4(p.b2 + wtiles[i] * 16 + cq);
+        if (tile_exists(i)) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) lds_store_quad<T>(bufX, ldx, m * 16 + pl, ch0, acc[m][i] + bias);
+            for (int m = 0; m < MT; ++m) lds_store_quad<T>(bufX, ldx, m * 16 + pl, ch0, acc[m][i] + bias);
+        }
     }
     __syncthreads();
     // o = (W2 d + b2) + x'   (identity rows were loaded with coalesced 16-byte loads above)
@@ -378,40 +399,67 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
     // FFN: C -> 4C -> chunk-add -> 2C -> C, the 4C-wide intermediate never leaves the CU
     zero_acc(acc);
     const int chunks = vtiles / (NW * NTV);
-    for (int ch = 0; ch < chunks; ++ch) {
-        floatx4 u[MT][2 * NTV];
-        zero_acc(u);
-        floatx4 blo[NTV], bhi[NTV];
+    floatx4 blo[NTV], bhi[NTV];
+    if constexpr (TR::kActPrescaled) {
 #pragma unroll
-        for (int j = 0; j < NTV; ++j) {   // biases requested before the GEMM that hides their latency
+        for (int j = 0; j < NTV; ++j) {
             blo[j] = load_f4(p.b3 + ut[j] * 16 + cq);
             bhi[j] = load_f4(p.b3 + ut[j] * 16 + cq + 2 * C);
         }
+    }
+    for (int ch = 0; ch < chunks; ++ch) {
+        floatx4 u[MT][2 * NTV];
+        if constexpr (TR::kActPrescaled) {   // the bias seeds the accumulators; the next chunk's is requested now
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int j = 0; j < NTV; ++j) {
+                    u[m][j] = blo[j];
+                    u[m][j + NTV] = bhi[j];
+                }
+            const int adv = (ch + 1 < chunks) ? NW * NTV * 16 : 0;
+#pragma unroll
+            for (int j = 0; j < NTV; ++j) {
+                blo[j] = load_f4(p.b3 + ut[j] * 16 + cq + adv);
+                bhi[j] = load_f4(p.b3 + ut[j] * 16 + cq + 2 * C + adv);
+            }
+        } else {
+            zero_acc(u);
+#pragma unroll
+            for (int j = 0; j < NTV; ++j) {   // biases requested before the GEMM that hides their latency
+                blo[j] = load_f4(p.b3 + ut[j] * 16 + cq);
+                bhi[j] = load_f4(p.b3 + ut[j] * 16 + cq + 2 * C);
+            }
+        }
         STAMP(tt);
-        if (!(p.ablate & 4))
+        if (!ABLATED(4))
             gemm_run<T, MT, 2 * NTV, PF3>(u, bufX, ldx, C / KG, pre3, reinterpret_cast<const frag_t*>(p.w3), C / KG, 0, ut, lane);
         STAMP(tt2);
         tg3 += tt2 - tt;
         WPre<T, NTW, PF> pre4;   // W4's groups for this chunk arrive underneath the activation epilogue
-        gemm_prefetch<T, NTW, PF>(pre4, VC / KG, reinterpret_cast<const frag_t*>(p.w4), 2 * C / KG, ch * (VC / KG), tiles, lane);
+        gemm_prefetch<T, NTW, PF>(pre4, VC / KG, reinterpret_cast<const frag_t*>(p.w4), 2 * C / KG, ch * (VC / KG), wtiles, lane);
 #pragma unroll
         for (int j = 0; j < NTV; ++j) {
             const int lch0 = (wave * NTV + j) * 16 + cq;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const floatx4 lo = u[m][j] + blo[j], hi = u[m][j + NTV] + bhi[j];
+                floatx4 lo = u[m][j], hi = u[m][j + NTV];
+                if constexpr (!TR::kActPrescaled) {
+                    lo = lo + blo[j];
+                    hi = hi + bhi[j];
+                }
                 floatx4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = TR::wsilu(lo[r]) + TR::wsilu(hi[r]);
+                for (int r = 0; r < 4; ++r) v[r] = TR::gate2(lo[r], hi[r]);
                 lds_store_quad<T>(bufV, ldv, m * 16 + pl, lch0, v);
             }
         }
         __syncthreads();
         STAMP(tt);
         tep += tt - tt2;
-        if (!(p.ablate & 8))
+        if (!ABLATED(8))
             gemm_run<T, MT, NTW, PF>(acc, bufV, ldv, VC / KG, pre4, reinterpret_cast<const frag_t*>(p.w4), 2 * C / KG,
-                                     ch * (VC / KG), tiles, lane);
+                                     ch * (VC / KG), wtiles, lane);
         if (ch + 1 < chunks) {   // next chunk's first W3 groups, requested before the barrier
 #pragma unroll
             for (int j = 0; j < 2 * NTV; ++j) ut[j] += NW * NTV;
@@ -427,11 +475,13 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         const int ch0 = tiles[i] * 16 + cq;
-        const floatx4 bias = load_f4(p.b4 + ch0);
+        const floatx4 bias = load_f4(p.b4 + wtiles[i] * 16 + cq);
+        if (tile_exists(i)) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const floatx4 o = lds_load_quad<T>(bufX, ldx, m * 16 + pl, ch0);
-            lds_store_quad<T>(bufX, ldx, m * 16 + pl, ch0, (acc[m][i] + bias) + o);
+            for (int m = 0; m < MT; ++m) {
+                const floatx4 o = lds_load_quad<T>(bufX, ldx, m * 16 + pl, ch0);
+                lds_store_quad<T>(bufX, ldx, m * 16 + pl, ch0, (acc[m][i] + bias) + o);
+            }
         }
     }
     __syncthreads();
@@ -456,6 +506,7 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
             *reinterpret_cast<Vec16*>(out + pix * p.ldo + c) = pack16<T>(r);
         }
     }
+#ifdef DCVC_DIAG
     if (p.stamps) {
         unsigned long long te = 0;
         __syncthreads();
@@ -476,6 +527,7 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
             }
         }
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -673,13 +725,13 @@ size_t tail_lds(int c)
     return TailLds<T, MT, TailCfg<MT, NTW, NW>::NTV, NW>::bytes(c);
 }
 
-template <typename T, int MT, int NTW, int NW>
+template <typename T, int MT, int NTW, int NW, bool RAG = false>
 int launch_tail(const TailParams& tp, int grid, int C, hipStream_t st)
 {
     const size_t lds = tail_lds<T, MT, NTW, NW>(C);
-    int rc = set_lds(dcb_tail_kernel<T, MT, NTW, NW>, lds);
+    int rc = set_lds(dcb_tail_kernel<T, MT, NTW, NW, RAG>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((dcb_tail_kernel<T, MT, NTW, NW>), dim3(grid), dim3(NW * 64), lds, st, tp);
+    hipLaunchKernelGGL((dcb_tail_kernel<T, MT, NTW, NW, RAG>), dim3(grid), dim3(NW * 64), lds, st, tp);
     return 0;
 }
 
@@ -690,9 +742,17 @@ int set_lds(K kernel, size_t bytes)
         dcvc::set_error("kernel needs %zu bytes of LDS (> 160 KiB)", bytes);
         return dcvc::E_ARG;
     }
-    if (bytes > 64 * 1024)
-        DCVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (bytes > 64 * 1024) {   // raise the kernel's dynamic-LDS limit once (not per launch, not inside a graph capture)
+        static std::mutex mu;
+        static std::unordered_map<const void*, size_t> granted;
+        const void* key = reinterpret_cast<const void*>(kernel);
+        std::lock_guard<std::mutex> lk(mu);
+        size_t& have = granted[key];
+        if (have < bytes) {
+            DCVC_HIP(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            have = bytes;
+        }
+    }
     return 0;
 }
 
@@ -765,9 +825,17 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         tp.stamps = d_stamps;
     }
     {
-        // (an eight-wave variant, NW = 8, was measured in round 1: 116 us vs 63 us - at <= 128 VGPRs the
-        // block spills; the kernel stays templated on NW for a register-frugal rewrite)
-        const int rc = launch_tail<T, MT, NTW, 4>(tp, grid, C, st);
+        // Widths of 384 and up (6+ channel tiles per wave) fit one workgroup per CU only.  Eight waves
+        // (two per SIMD, half the channel tiles each, <= 256 VGPRs) give every SIMD a second wave of the
+        // same tile to switch to: 144 -> 117 us at C=384, 136x240.  At C <= 256 two independent 4-wave
+        // workgroups per CU do that job better (8 waves there measured 116 us vs 63 us).
+        int rc;
+        if constexpr (NTW >= 6 && NTW % 2 == 0 && sizeof(T) == 2)
+            rc = launch_tail<T, MT, NTW / 2, 8>(tp, grid, C, st);
+        else if constexpr (NTW == 5 && sizeof(T) == 2)
+            rc = launch_tail<T, MT, 3, 8, true>(tp, grid, C, st);   // 20 tiles on 8 waves: 4 waves x 3 + 4 waves x 2
+        else
+            rc = launch_tail<T, MT, NTW, 4>(tp, grid, C, st);
         if (rc) return rc;
     }
     DCVC_LAUNCH_CHECK();
@@ -915,18 +983,22 @@ int dcvc_dcb_create(int dtype, int cin, int c, int shortcut, const float* adapto
         rc |= pack_any(dtype, h->wa, Cp, Kp, [&](int n, int k) { return (n < C && k < cin) ? adaptor_w[(size_t)n * cin + k] : 0.f; });
         rc |= upload_f32(h->ba, Cp, [&](int n) { return n < C ? adaptor_b[n] : 0.f; });
     }
-    rc |= pack_any(dtype, h->w1, Cp, Cp, [&](int n, int k) { return (n < C && k < C) ? w1[(size_t)n * C + k] : 0.f; });
-    rc |= upload_f32(h->b1, Cp, [&](int n) { return n < C ? b1[n] : 0.f; });
-    auto dwget = [&](int i) { const int t = i / Cp, ch = i % Cp; return ch < C ? wd[(size_t)ch * 9 + t] : 0.f; };
+    // fp16 mode evaluates both activations on pre-scaled pre-activations (Traits<half_t>::gate / gate2):
+    // dc.0 and ffn.0 are packed multiplied by kAct, their consumers (depthwise taps, ffn.2) divided by
+    // it; exact mode packs everything unchanged (ka == 1)
+    const float ka = dtype == DCVC_F16 ? Traits<half_t>::kAct : 1.0f;
+    rc |= pack_any(dtype, h->w1, Cp, Cp, [&](int n, int k) { return (n < C && k < C) ? ka * w1[(size_t)n * C + k] : 0.f; });
+    rc |= upload_f32(h->b1, Cp, [&](int n) { return n < C ? ka * b1[n] : 0.f; });
+    auto dwget = [&](int i) { const int t = i / Cp, ch = i % Cp; return ch < C ? wd[(size_t)ch * 9 + t] / ka : 0.f; };
     rc |= dtype == DCVC_F16 ? upload_T<half_t>(h->wd, 9 * Cp, dwget) : upload_T<float>(h->wd, 9 * Cp, dwget);
     rc |= upload_f32(h->bd, Cp, [&](int n) { return n < C ? bd[n] : 0.f; });
     rc |= pack_any(dtype, h->w2, Cp, Cp, [&](int n, int k) { return (n < C && k < C) ? w2[(size_t)n * C + k] : 0.f; });
     rc |= upload_f32(h->b2, Cp, [&](int n) { return n < C ? b2[n] : 0.f; });
     // ffn.0: logical rows [0,2C) pair with rows [2C,4C) (WSiLUChunkAdd); physical halves are 2*Cp wide
     auto u_row = [&](int n) { const int half = n / (2 * Cp), cc = n % (2 * Cp); return cc < 2 * C ? half * 2 * C + cc : -1; };
-    rc |= pack_any(dtype, h->w3, 4 * Cp, Cp, [&](int n, int k) { const int rr = u_row(n); return (rr >= 0 && k < C) ? w3[(size_t)rr * C + k] : 0.f; });
-    rc |= upload_f32(h->b3, 4 * Cp, [&](int n) { const int rr = u_row(n); return rr >= 0 ? b3[rr] : 0.f; });
-    rc |= pack_any(dtype, h->w4, Cp, 2 * Cp, [&](int n, int k) { return (n < C && k < 2 * C) ? w4[(size_t)n * 2 * C + k] : 0.f; });
+    rc |= pack_any(dtype, h->w3, 4 * Cp, Cp, [&](int n, int k) { const int rr = u_row(n); return (rr >= 0 && k < C) ? ka * w3[(size_t)rr * C + k] : 0.f; });
+    rc |= upload_f32(h->b3, 4 * Cp, [&](int n) { const int rr = u_row(n); return rr >= 0 ? ka * b3[rr] : 0.f; });
+    rc |= pack_any(dtype, h->w4, Cp, 2 * Cp, [&](int n, int k) { return (n < C && k < 2 * C) ? w4[(size_t)n * 2 * C + k] / ka : 0.f; });
     rc |= upload_f32(h->b4, Cp, [&](int n) { return n < C ? b4[n] : 0.f; });
     if (rc) return rc < 0 ? rc : dcvc::E_MEM;
     *out = h.release();

@@ -74,6 +74,14 @@ class EncodeDecodePipeline:
         import torch
         self.encoder, self.decoder, self.device, self.depth = encoder, decoder, device, depth
         self.enc_stream, self.dec_stream = torch.cuda.Stream(device), torch.cuda.Stream(device)
+        self._warm = 0
+
+    def _captured(self):
+        eg, dg = self.encoder.p_net._graphs, self.decoder.p_net._graphs
+        if not (eg.enabled and dg.enabled):
+            return True
+        done = all(("i" in v and "p" in v) for v in (eg.variants("enc_back"), dg.variants("dec_4")))
+        return done or self._warm >= 40      # (an all-intra sequence never captures the "p" variant)
 
     def run(self, frames, on_packet=None, on_frame=None):
         """frames: iterable of padded model inputs (device tensors, ready on the calling stream).
@@ -83,6 +91,25 @@ class EncodeDecodePipeline:
         import threading
         import torch
         torch.cuda.current_stream().synchronize()
+        frames = iter(frames)
+        # HIP graph capture (GraphCache) must not overlap the other stage's work: a device synchronisation or
+        # a free on another thread invalidates a capture in flight.  Until both P-frame variants of both
+        # stages are captured (normally: the first three frames) the stages run one after the other here.
+        while not self._captured():
+            x = next(frames, None)
+            if x is None:
+                return
+            with torch.cuda.stream(self.enc_stream):
+                pkt = self.encoder.encode(x)
+                if on_packet is not None:
+                    on_packet(pkt)
+            self.enc_stream.synchronize()
+            with torch.cuda.stream(self.dec_stream):
+                x_hat = self.decoder.decode(pkt)
+                if on_frame is not None:
+                    on_frame(x_hat)
+            self.dec_stream.synchronize()
+            self._warm += 1
         q = queue.Queue(maxsize=self.depth)
         errors = []
 

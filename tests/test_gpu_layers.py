@@ -96,6 +96,25 @@ def test_depth_conv_block(case, dtype):
     compare(got[:, :, :c], ref, dtype, f"dcb {case}")
 
 
+@pytest.mark.parametrize("c", [128, 256, 320, 368, 512])
+def test_depth_conv_block_large_map_fp16(c):
+    """Maps of 12 000+ pixels take the 64-pixel-tile kernels (two workgroups per CU up to 256 channels,
+    eight-wave workgroups above, the ragged one at 320): same check as above, edge tiles included."""
+    from opendcvc_amd import nn
+    H, W = 101, 123
+    rng = _rng(300 + c)
+    sd = make_dcb_weights(rng, "m", c, c, False)
+    x = rng.standard_normal((H, W, c)).astype(np.float16).astype(np.float32)
+    q = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    ref = O.Net(sd).dcb(x, "m", shortcut=True, q=q)
+    blk = nn.DepthConvBlock(sd, "m", torch.float16, shortcut=True)
+    out = blk(to_dev(x, blk.cin_p, torch.float16), quant=torch.from_numpy(q).cuda())
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    assert not np.any(got[:, :, c:]), "pad channels must stay zero"
+    compare(got[:, :, :c], ref, torch.float16, f"dcb large map c={c}")
+
+
 def test_dcb_writes_into_concat_slice():
     from opendcvc_amd import nn
     rng = _rng(5)
