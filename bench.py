@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the roofline leg (what profiles/r01_roofline_kernel_stats.csv was collected on)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,6 +158,10 @@ def main():
     two = use_two_entropy_coders(HEIGHT, WIDTH)
     for m in (ie, pe, idec, pdec):
         m.set_use_two_entropy_coders(two)
+    if args.roofline_only:
+        pe._ensure_layers()
+        print(json.dumps({"roofline": roofline_leg(pe, device, dtype)}), flush=True)
+        return
     frames = make_frames(rank, dtype, device)
     enc = SequenceEncoder(ie, pe, QP, intra_period=GOP, reset_interval=GOP)
     dec = SequenceDecoder(idec, pdec, HEIGHT, WIDTH, two)

@@ -32,8 +32,15 @@ for m, tag in ((pe, "enc"), (pdec, "dec")):
     ec = m.entropy_coder
     for n in ("encode_y", "encode_z", "flush", "get_encoded_stream", "set_stream", "decode_and_get_y", "get_decoded", "reset"):
         timed(ec, n, f"{tag}.ec.{n}")
-    for n in ("_apply_feature_adaptor", "_extractor_part1", "_extractor_part2", "_prior_params", "_spatial_prior", "_decoder", "_recon", "_decode_step"):
+    for n in ("_stage_q", "_stage_reference", "_unshuffle8"):
         timed(m, n, f"{tag}.{n}")
+    run = m._graphs.run
+    def timed_run(key, fn, run=run, tag=tag):
+        t0 = time.perf_counter()
+        r = run(key, fn)
+        T[f"{tag}.run {key[0]}"] = T.get(f"{tag}.run {key[0]}", 0.0) + time.perf_counter() - t0
+        return r
+    m._graphs.run = timed_run
 lib = _lib.lib()
 orig_sync = lib.dcvc_stream_sync
 pkts = []

@@ -38,15 +38,31 @@ def wrap(obj, name, label):
     setattr(obj, name, w)
 
 
+def wrap_runs(model, tag):
+    """label every captured run (GraphCache.run) by its name"""
+    f = model._graphs.run
+
+    def w(key, fn):
+        if not ON[0]:
+            return f(key, fn)
+        t0 = time.perf_counter()
+        r = f(key, fn)
+        t1 = time.perf_counter()
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        LOG.append((f"{tag}.run {key[0]}", t0 - T0[0], t1 - T0[0], ev))
+        return r
+    model._graphs.run = w
+
+
 for m, tag in ((pe, "enc"), (pdec, "dec")):
     ec = m.entropy_coder
     for n in ("encode_y", "encode_z", "flush", "get_encoded_stream", "set_stream", "decode_z", "decode_and_get_y",
               "get_decoded", "reset"):
         wrap(ec, n, f"{tag}.ec.{n}")
-    for n in ("_apply_feature_adaptor", "_extractor_part1", "_extractor_part2", "_prior_params", "_spatial_prior",
-              "_decoder", "_recon", "_decode_step_begin", "_prior_enc_step", "_prior_dec_restore", "_quantize_z",
-              "_z_to_device", "_d2h", "_prior_finish"):
+    for n in ("_stage_q", "_stage_reference", "_unshuffle8"):
         wrap(m, n, f"{tag}.{n}")
+    wrap_runs(m, tag)
 _es = torch.cuda.Event.synchronize
 
 
