@@ -56,6 +56,71 @@ __global__ void unshuffle8_kernel(const T* x, int C, int H, int W, T* out, int64
     out[((int64_t)(y >> 3) * W8 + (xw >> 3)) * ldo + c * 64 + (y & 7) * 8 + (xw & 7)] = x[i];
 }
 
+// PixelUnshuffle(8) / PixelShuffle(8) through LDS: a block moves 32 output pixels of one row of the HWC map
+// = C x 8 image rows x 256 columns.  Image rows are read / written as contiguous 512-byte (f16) runs,
+// the HWC side as one contiguous run of 32 pixels x 64C channels; both sides use 16-byte accesses.
+constexpr int S8_PIX = 32;
+
+template <typename T>
+__global__ __launch_bounds__(EB) void unshuffle8_tiled_kernel(const T* x, int C, int H, int W, T* out, int64_t ldo)
+{
+    constexpr int V = Traits<T>::kVec, COLS = S8_PIX * 8, VPR = COLS / V;   // vectors per image-row segment
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* tile = reinterpret_cast<T*>(smem);                                   // [C*8][COLS]
+    const int W8 = W / 8, segs = (W8 + S8_PIX - 1) / S8_PIX;
+    const int oh = blockIdx.x / segs, ow0 = (blockIdx.x % segs) * S8_PIX;
+    const int npix = min(S8_PIX, W8 - ow0);
+    const int rows = C * 8;
+    for (int it = threadIdx.x; it < rows * VPR; it += EB) {
+        const int r = it / VPR, v = it - r * VPR;                          // r = c*8 + (y & 7)
+        if (v * V < npix * 8) {
+            const int c = r >> 3, y = oh * 8 + (r & 7);
+            *reinterpret_cast<Vec16*>(tile + r * COLS + v * V) =
+                *reinterpret_cast<const Vec16*>(x + ((int64_t)c * H + y) * W + ow0 * 8 + v * V);
+        }
+    }
+    __syncthreads();
+    constexpr int G = 8 / V;                                               // 16-byte vectors per 8-element group
+    for (int it = threadIdx.x; it < npix * rows * G; it += EB) {
+        const int pix = it / (rows * G), rem = it - pix * (rows * G), r = rem / G, g = rem - r * G;
+        *reinterpret_cast<Vec16*>(out + ((int64_t)oh * W8 + ow0 + pix) * ldo + r * 8 + g * V) =
+            *reinterpret_cast<const Vec16*>(tile + r * COLS + pix * 8 + g * V);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(EB) void shuffle8_tiled_kernel(const T* x, int64_t ldx, const float* bias, int C, int H, int W,
+                                                           int do_clamp, T* out)
+{
+    constexpr int V = Traits<T>::kVec, COLS = S8_PIX * 8, VPR = COLS / V, G = 8 / V;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* tile = reinterpret_cast<T*>(smem);                                   // [C*8][COLS]
+    const int segs = (W + S8_PIX - 1) / S8_PIX;
+    const int oh = blockIdx.x / segs, ow0 = (blockIdx.x % segs) * S8_PIX;
+    const int npix = min(S8_PIX, W - ow0);
+    const int rows = C * 8, HO = H * 8, WO = W * 8;
+    for (int it = threadIdx.x; it < npix * rows * G; it += EB) {
+        const int pix = it / (rows * G), rem = it - pix * (rows * G), r = rem / G, g = rem - r * G;
+        float v[V];
+        unpack16<T>(*reinterpret_cast<const Vec16*>(x + ((int64_t)oh * W + ow0 + pix) * ldx + r * 8 + g * V), v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            if (bias) v[j] = v[j] + bias[r * 8 + g * V + j];
+            if (do_clamp) v[j] = clampf(v[j], 0.f, 1.f);
+        }
+        *reinterpret_cast<Vec16*>(tile + r * COLS + pix * 8 + g * V) = pack16<T>(v);
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < rows * VPR; it += EB) {
+        const int r = it / VPR, v = it - r * VPR;
+        if (v * V < npix * 8) {
+            const int c = r >> 3, y = oh * 8 + (r & 7);
+            *reinterpret_cast<Vec16*>(out + ((int64_t)c * HO + y) * WO + ow0 * 8 + v * V) =
+                *reinterpret_cast<const Vec16*>(tile + r * COLS + v * V);
+        }
+    }
+}
+
 template <typename T>
 __global__ void shuffle8_kernel(const T* x, int64_t ldx, const float* bias, int C, int H, int W, int do_clamp, T* out)
 {
@@ -90,6 +155,23 @@ __global__ void scale_channels_kernel(const T* x, int64_t ldx, const float* q, i
     const int c = (int)(i % C);
     const int64_t p = i / C;
     st(out, p * ldo + c, ld(x, p * ldx + c) * q[c]);
+}
+
+// same, 16 bytes per thread (C, ldx, ldo multiples of the vector width, 16-byte aligned bases)
+template <typename T>
+__global__ void scale_channels_vec_kernel(const T* x, int64_t ldx, const float* q, int64_t P, int C, T* out, int64_t ldo)
+{
+    constexpr int V = Traits<T>::kVec;
+    const int gc = C / V;
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= P * gc) return;
+    const int c = (int)(i % gc) * V;
+    const int64_t p = i / gc;
+    float v[V];
+    unpack16<T>(*reinterpret_cast<const Vec16*>(x + p * ldx + c), v);
+#pragma unroll
+    for (int j = 0; j < V; ++j) v[j] = v[j] * q[c + j];
+    *reinterpret_cast<Vec16*>(out + p * ldo + c) = pack16<T>(v);
 }
 
 template <typename T>
@@ -205,7 +287,7 @@ __global__ void z_from_int8_kernel(const int8_t* z_chw, int64_t HW, int C, T* ou
 // One block = 64 consecutive pixels x all collapsed channels.  Phase 1 walks (pixel, channel) with
 // the channel fastest (coalesced HWC reads / y_hat writes); the packed symbols go through LDS so
 // phase 2 can write them pixel-fastest in the reference's CHW order.
-constexpr int PT = 64;
+constexpr int PT = 16;
 
 struct PriorEncArgs {
     int n_groups, step, q_mode;
@@ -521,7 +603,16 @@ int dcvc_unshuffle8(int dtype, const void* x, int C, int H, int W, void* out, in
     DCVC_REQUIRE(x && out && H % 8 == 0 && W % 8 == 0 && ldo >= C * 64, "dcvc_unshuffle8: bad arguments");
     return typed(dtype, [&](auto tag) {
         using T = decltype(tag);
-        unshuffle8_kernel<T><<<nblocks((int64_t)C * H * W), EB, 0, (hipStream_t)stream>>>((const T*)x, C, H, W, (T*)out, ldo);
+        constexpr int V = Traits<T>::kVec;
+        const size_t lds = (size_t)C * 8 * S8_PIX * 8 * sizeof(T);
+        const bool tiled = W % 8 == 0 && H % 8 == 0 && (W % V) == 0 && ldo % V == 0 && lds <= 64 * 1024 &&
+                           ((uintptr_t)x | (uintptr_t)out) % 16 == 0;
+        if (tiled) {
+            const int segs = (W / 8 + S8_PIX - 1) / S8_PIX;
+            unshuffle8_tiled_kernel<T><<<(H / 8) * segs, EB, lds, (hipStream_t)stream>>>((const T*)x, C, H, W, (T*)out, ldo);
+        } else {
+            unshuffle8_kernel<T><<<nblocks((int64_t)C * H * W), EB, 0, (hipStream_t)stream>>>((const T*)x, C, H, W, (T*)out, ldo);
+        }
     });
 }
 
@@ -531,7 +622,15 @@ int dcvc_shuffle8_clamp(int dtype, const void* x, int64_t ld_, const float* bias
     DCVC_REQUIRE(x && out && ld_ >= C * 64, "dcvc_shuffle8_clamp: bad arguments");
     return typed(dtype, [&](auto tag) {
         using T = decltype(tag);
-        shuffle8_kernel<T><<<nblocks((int64_t)C * H * W * 64), EB, 0, (hipStream_t)stream>>>((const T*)x, ld_, bias, C, H, W, do_clamp, (T*)out);
+        constexpr int V = Traits<T>::kVec;
+        const size_t lds = (size_t)C * 8 * S8_PIX * 8 * sizeof(T);
+        const bool tiled = ld_ % V == 0 && lds <= 64 * 1024 && ((uintptr_t)x | (uintptr_t)out) % 16 == 0;
+        if (tiled) {
+            const int segs = (W + S8_PIX - 1) / S8_PIX;
+            shuffle8_tiled_kernel<T><<<H * segs, EB, lds, (hipStream_t)stream>>>((const T*)x, ld_, bias, C, H, W, do_clamp, (T*)out);
+        } else {
+            shuffle8_kernel<T><<<nblocks((int64_t)C * H * W * 64), EB, 0, (hipStream_t)stream>>>((const T*)x, ld_, bias, C, H, W, do_clamp, (T*)out);
+        }
     });
 }
 
@@ -552,7 +651,12 @@ int dcvc_scale_channels(int dtype, const void* x, int64_t ldx, const float* q, i
     DCVC_REQUIRE(x && out && q, "dcvc_scale_channels: null pointer");
     return typed(dtype, [&](auto tag) {
         using T = decltype(tag);
-        scale_channels_kernel<T><<<nblocks(P * C), EB, 0, (hipStream_t)stream>>>((const T*)x, ldx, q, P, C, (T*)out, ldo);
+        constexpr int V = Traits<T>::kVec;
+        const bool vec = C % V == 0 && ldx % V == 0 && ldo % V == 0 && ((uintptr_t)x | (uintptr_t)out) % 16 == 0;
+        if (vec)
+            scale_channels_vec_kernel<T><<<nblocks(P * (C / V)), EB, 0, (hipStream_t)stream>>>((const T*)x, ldx, q, P, C, (T*)out, ldo);
+        else
+            scale_channels_kernel<T><<<nblocks(P * C), EB, 0, (hipStream_t)stream>>>((const T*)x, ldx, q, P, C, (T*)out, ldo);
     });
 }
 

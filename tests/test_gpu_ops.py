@@ -137,3 +137,28 @@ def test_subpel_proxy_vs_reference(g, name, pad):
     p = ops.SubpelConv2xProxy()
     p.set_param(cu(w["conv.0.weight"]), cu(w["conv.0.bias"]), pad)
     np.testing.assert_allclose(p.forward(cu(g[name + ".x"])).cpu().numpy(), g[name + ".y"], **TOL)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("hw", [(16, 16), (64, 264), (136, 1928), (8, 4096)])
+def test_unshuffle8_shuffle8_layout_kernels(dtype, hw):
+    """dcvc_unshuffle8 == F.pixel_unshuffle(x, 8) in HWC; dcvc_shuffle8_clamp == clamp(F.pixel_shuffle(x + bias, 8))
+    (LDS-tiled kernels: full and ragged 32-pixel segments, odd row counts, both storage types)."""
+    import ctypes
+    from opendcvc_amd import _lib, nn as L
+    H, W = hw
+    lib = _lib.lib()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gen = torch.Generator().manual_seed(H * 7 + W)
+    x = (torch.rand((1, 3, H, W), generator=gen) * 2 - 0.5).to(dtype).cuda()
+    out = torch.zeros((H // 8, W // 8, 192), dtype=dtype, device="cuda")
+    _lib.check(lib.dcvc_unshuffle8(L.dtype_code(dtype), L._p(x), 3, H, W, L._p(out), 192, st), "unshuffle8")
+    want = torch.nn.functional.pixel_unshuffle(x, 8)[0].permute(1, 2, 0).contiguous()
+    assert torch.equal(out, want)
+    bias = torch.rand(192, generator=gen).cuda() - 0.5
+    back = torch.empty((1, 3, H, W), dtype=dtype, device="cuda")
+    _lib.check(lib.dcvc_shuffle8_clamp(L.dtype_code(dtype), L._p(out), 192, L._p(bias), 3, H // 8, W // 8, 1, L._p(back), st),
+               "shuffle8_clamp")
+    ref = (out.float() + bias).to(dtype).float().clamp(0, 1).to(dtype)
+    ref = torch.nn.functional.pixel_shuffle(ref.permute(2, 0, 1)[None], 8)
+    assert torch.equal(back, ref)
