@@ -68,6 +68,19 @@ size_t dcvc_dcb_scratch_bytes(const dcvc_dcb* h, int H, int W);
 int dcvc_dcb_forward(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, const void* x1,
                      int64_t ld1, int c1, int H, int W, const float* quant, void* out, int64_t ldo,
                      void* scratch, void* stream);
+/* The same block inside a run of DepthConvBlocks that feed each other directly (the Sequential stacks of
+ * video_model.py / image_model.py): the first 1x1 conv + WSiLU of a block is pointwise, so the PREVIOUS block
+ * can compute it on its output tile before that tile leaves the CU.
+ *   next != NULL : also produce next's pre-depthwise activation (needs: same width and type, next without
+ *                  adaptor, this block without shortcut and without quant step); results are bit-identical
+ *                  to calling the two blocks separately.
+ *   head_done    : this block's own pre-depthwise activation was produced that way by the previous call.
+ *   a_slot       : 0 / 1, alternating along the run (which half of the scratch holds this block's activation).
+ * All calls of a run use the same scratch.  dcvc_dcb_forward(...) == (..., 0, 0, NULL). */
+int dcvc_dcb_forward_chained(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, const void* x1,
+                             int64_t ld1, int c1, int H, int W, const float* quant, void* out,
+                             int64_t ldo, void* scratch, void* stream, int head_done, int a_slot,
+                             const dcvc_dcb* next);
 
 /* Measurement aid (bench.py roofline leg): runs the block `iters` times on `stream` with HIP events
  * recorded on that stream around each of its two kernels; returns the mean durations in ms. */

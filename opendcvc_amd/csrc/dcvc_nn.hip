@@ -179,6 +179,12 @@ struct TailParams {
     const float* q;      // device, c_log entries, or NULL
     void* out;
     long ldo;
+    // chained blocks: the NEXT block's first 1x1 conv + activation, computed on this block's output tile
+    // while it is still in LDS (pointwise, so no halo is needed); NULL = not fused
+    const void* nw1;
+    const float* nb1;
+    void* na_out;
+    long nlda;
     int ablate;          // debug: bit0 skip dw, bit1 skip GEMM2, bit2 skip FFN GEMM3, bit3 skip FFN GEMM4
     unsigned long long* stamps;   // diagnostic build only (DCVC_STAMPS): 8 cycle counters per workgroup
 };
@@ -506,6 +512,37 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
             *reinterpret_cast<Vec16*>(out + pix * p.ldo + c) = pack16<T>(r);
         }
     }
+    if (p.nw1 != nullptr) {
+        // Fused head of the next DepthConvBlock: a' = gate(W1' r + b1') on the tile still in bufX (the host only
+        // chains when this block has neither shortcut nor quant step, so bufX holds exactly the values stored
+        // above).  Same k order and epilogue as dcb_head_kernel -> bit-identical to the unfused launch.
+        floatx4 acc1[MT][NTW];
+        zero_acc(acc1);
+        gemm_acc<T, MT, NTW, PF>(acc1, bufX, ldx, C / KG, reinterpret_cast<const frag_t*>(p.nw1), C / KG, 0, wtiles, lane);
+        __syncthreads();   // every wave has finished reading r
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const int ch0 = tiles[i] * 16 + cq;
+            const floatx4 bias = load_f4(p.nb1 + wtiles[i] * 16 + cq);
+            if (tile_exists(i)) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    floatx4 v = acc1[m][i] + bias;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = TR::gate(v[r]);
+                    lds_store_quad<T>(bufX, ldx, m * 16 + pl, ch0, v);
+                }
+            }
+        }
+        __syncthreads();
+        T* na = reinterpret_cast<T*>(p.na_out);
+        for (int it = tid; it < M * GC; it += NTHREADS_) {
+            const int m = it / GC, c = (it - m * GC) * V;
+            const int y = ty0 + m / TW, x = tx0 + m % TW;
+            if (y < p.H && x < p.W)
+                *reinterpret_cast<Vec16*>(na + ((long)y * p.W + x) * p.nlda + c) = lds_load_vec<T>(bufX, ldx, m, c);
+        }
+    }
 #ifdef DCVC_DIAG
     if (p.stamps) {
         unsigned long long te = 0;
@@ -756,15 +793,24 @@ int set_lds(K kernel, size_t bytes)
     return 0;
 }
 
+// chained launches: this block's `a` lives in scratch slot a_slot (already there if head_done: the previous
+// block's tail produced it); if next != NULL this block's tail also produces next's `a` in the other slot
+struct ChainArgs {
+    int head_done = 0, a_slot = 0;
+    const dcvc_dcb* next = nullptr;
+};
+
 template <typename T, int MT, int NTW>
 int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float* quant, void* out, int64_t ldo,
-               void* scratch, hipStream_t st, hipEvent_t* ev = nullptr)
+               void* scratch, hipStream_t st, hipEvent_t* ev = nullptr, ChainArgs ch = ChainArgs())
 {
     const int C = h->c_p;
     const int grid = ((H + Tile<MT>::TH - 1) / Tile<MT>::TH) * ((W + Tile<MT>::TW - 1) / Tile<MT>::TW);
     const size_t P = (size_t)H * W;
-    T* a_buf = reinterpret_cast<T*>(scratch);
-    T* id_buf = a_buf + P * C;
+    T* slots = reinterpret_cast<T*>(scratch);           // [a slot 0 | a slot 1 | x' of an adaptor block]
+    T* a_buf = slots + (size_t)(ch.a_slot & 1) * P * C;
+    T* a_next = slots + (size_t)((ch.a_slot & 1) ^ 1) * P * C;
+    T* id_buf = slots + 2 * P * C;
     HeadParams hp{};
     hp.src = src;
     hp.H = H;
@@ -780,7 +826,9 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     hp.lda = C;
     const int kin = src.c0 + src.c1;
     if (ev) DCVC_HIP(hipEventRecord(ev[0], st));
-    if (h->adapt) {
+    if (ch.head_done) {
+        // `a` was written by the previous block's tail
+    } else if (h->adapt) {
         const size_t lds = head_lds<T, MT>(kin, C, true);
         int rc = set_lds(dcb_head_kernel<T, MT, NTW, true>, lds);
         if (rc) return rc;
@@ -814,6 +862,12 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     tp.q = quant;
     tp.out = out;
     tp.ldo = ldo;
+    if (ch.next) {
+        tp.nw1 = ch.next->w1.p;
+        tp.nb1 = (const float*)ch.next->b1.p;
+        tp.na_out = a_next;
+        tp.nlda = C;
+    }
     {
         static const int abl = getenv("DCVC_ABLATE") ? atoi(getenv("DCVC_ABLATE")) : 0;
         tp.ablate = abl;
@@ -882,16 +936,16 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
 
 template <typename T, int MT>
 int dispatch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float* quant, void* out, int64_t ldo,
-                 void* scratch, hipStream_t st, hipEvent_t* ev = nullptr)
+                 void* scratch, hipStream_t st, hipEvent_t* ev = nullptr, ChainArgs ch = ChainArgs())
 {
     switch (h->c_p / 64) {
-    case 1: return launch_dcb<T, MT, 1>(h, src, H, W, quant, out, ldo, scratch, st, ev);
-    case 2: return launch_dcb<T, MT, 2>(h, src, H, W, quant, out, ldo, scratch, st, ev);
-    case 3: return launch_dcb<T, MT, 3>(h, src, H, W, quant, out, ldo, scratch, st, ev);
-    case 4: return launch_dcb<T, MT, 4>(h, src, H, W, quant, out, ldo, scratch, st, ev);
-    case 5: return launch_dcb<T, MT, 5>(h, src, H, W, quant, out, ldo, scratch, st, ev);
-    case 6: return launch_dcb<T, MT, 6>(h, src, H, W, quant, out, ldo, scratch, st, ev);
-    case 8: return launch_dcb<T, MT, 8>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+    case 1: return launch_dcb<T, MT, 1>(h, src, H, W, quant, out, ldo, scratch, st, ev, ch);
+    case 2: return launch_dcb<T, MT, 2>(h, src, H, W, quant, out, ldo, scratch, st, ev, ch);
+    case 3: return launch_dcb<T, MT, 3>(h, src, H, W, quant, out, ldo, scratch, st, ev, ch);
+    case 4: return launch_dcb<T, MT, 4>(h, src, H, W, quant, out, ldo, scratch, st, ev, ch);
+    case 5: return launch_dcb<T, MT, 5>(h, src, H, W, quant, out, ldo, scratch, st, ev, ch);
+    case 6: return launch_dcb<T, MT, 6>(h, src, H, W, quant, out, ldo, scratch, st, ev, ch);
+    case 8: return launch_dcb<T, MT, 8>(h, src, H, W, quant, out, ldo, scratch, st, ev, ch);
     default: dcvc::set_error("DepthConvBlock width %d not instantiated", h->c_p); return dcvc::E_ARG;
     }
 }
@@ -934,18 +988,18 @@ static int pick_mt_f16(int H, int W, int c_p)
 
 template <int MT>
 int dispatch_dcb_f16(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float* quant, void* out, int64_t ldo,
-                     void* scratch, hipStream_t st, hipEvent_t* ev)
+                     void* scratch, hipStream_t st, hipEvent_t* ev, ChainArgs ch)
 {
-    return dispatch_dcb<half_t, MT>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+    return dispatch_dcb<half_t, MT>(h, src, H, W, quant, out, ldo, scratch, st, ev, ch);
 }
 
 static int run_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float* quant, void* out, int64_t ldo,
-                   void* scratch, hipStream_t st, hipEvent_t* ev)
+                   void* scratch, hipStream_t st, hipEvent_t* ev, ChainArgs ch = ChainArgs())
 {
-    if (h->dtype != DCVC_F16) return dispatch_dcb<float, 2>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+    if (h->dtype != DCVC_F16) return dispatch_dcb<float, 2>(h, src, H, W, quant, out, ldo, scratch, st, ev, ch);
     switch (pick_mt_f16(H, W, h->c_p)) {
-    case 2: return dispatch_dcb_f16<2>(h, src, H, W, quant, out, ldo, scratch, st, ev);
-    default: return dispatch_dcb_f16<4>(h, src, H, W, quant, out, ldo, scratch, st, ev);
+    case 2: return dispatch_dcb_f16<2>(h, src, H, W, quant, out, ldo, scratch, st, ev, ch);
+    default: return dispatch_dcb_f16<4>(h, src, H, W, quant, out, ldo, scratch, st, ev, ch);
     }
 }
 
@@ -1010,13 +1064,25 @@ void dcvc_dcb_destroy(dcvc_dcb* h) { delete h; }
 size_t dcvc_dcb_scratch_bytes(const dcvc_dcb* h, int H, int W)
 {
     if (!h) return 0;
-    return (size_t)H * W * h->c_p * dcvc::elem_size(h->dtype) * 2;
+    return (size_t)H * W * h->c_p * dcvc::elem_size(h->dtype) * 3;   // two `a` slots (chained blocks alternate) + x'
 }
 
 int dcvc_dcb_forward(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, const void* x1, int64_t ld1, int c1,
                      int H, int W, const float* quant, void* out, int64_t ldo, void* scratch, void* stream)
 {
+    return dcvc_dcb_forward_chained(h, x0, ld0, c0, x1, ld1, c1, H, W, quant, out, ldo, scratch, stream, 0, 0, nullptr);
+}
+
+int dcvc_dcb_forward_chained(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, const void* x1, int64_t ld1, int c1,
+                             int H, int W, const float* quant, void* out, int64_t ldo, void* scratch, void* stream,
+                             int head_done, int a_slot, const dcvc_dcb* next)
+{
     DCVC_REQUIRE(h && x0 && out && scratch, "dcvc_dcb_forward: null pointer");
+    DCVC_REQUIRE(!head_done || !h->adapt, "dcvc_dcb_forward_chained: a block with adaptor computes its own head");
+    if (next)
+        DCVC_REQUIRE(!next->adapt && next->c_p == h->c_p && next->dtype == h->dtype && !quant && !h->shortcut,
+                     "dcvc_dcb_forward_chained: cannot fuse the next block's head (needs same width and type, no "
+                     "adaptor there, no shortcut / quant step here)");
     DCVC_REQUIRE(H > 0 && W > 0, "dcvc_dcb_forward: empty input %dx%d", H, W);
     DCVC_REQUIRE(c0 % 32 == 0 && c1 % 32 == 0 && c0 + c1 == h->cin_p,
                  "dcvc_dcb_forward: input channels %d+%d do not match the block (%d physical)", c0, c1, h->cin_p);
@@ -1028,7 +1094,11 @@ int dcvc_dcb_forward(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, con
                  "dcvc_dcb_forward: inputs must be 16-byte aligned");
     SrcPair src{x0, (long)ld0, c0, x1, (long)ld1, c1};
     hipStream_t st = (hipStream_t)stream;
-    return run_dcb(h, src, H, W, quant, out, ldo, scratch, st, nullptr);
+    ChainArgs ch;
+    ch.head_done = head_done;
+    ch.a_slot = a_slot;
+    ch.next = next;
+    return run_dcb(h, src, H, W, quant, out, ldo, scratch, st, nullptr, ch);
 }
 
 int dcvc_dcb_profile(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, int H, int W, void* out, int64_t ldo,

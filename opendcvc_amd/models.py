@@ -369,7 +369,7 @@ class DMC(CompressionModel):
     # ---- sub-networks
     def _extractor_part1(self, f, q_feature):
         n = self._layers
-        x1 = n["fe1"][1](n["fe1"][0](f))
+        x1 = L.dcb_chain(n["fe1"], f)
         ctx_t = torch.empty_like(x1)
         H, W, C, ld = L._geom(x1)
         check(_lib.lib().dcvc_scale_channels(L.dtype_code(x1.dtype), L._p(x1), ld, L._p(q_feature), H * W, C,
@@ -377,9 +377,7 @@ class DMC(CompressionModel):
         return x1, ctx_t
 
     def _extractor_part2(self, x1):
-        for blk in self._layers["fe2"]:
-            x1 = blk(x1)
-        return x1
+        return L.dcb_chain(self._layers["fe2"], x1)
 
     def _prior_params(self, z_hat, ctx_t, yh, yw):
         """res_prior_param_decoder (video_model.py:279-286) -> [yh, yw, 384] = q_dec | scales | means"""
@@ -391,25 +389,20 @@ class DMC(CompressionModel):
         else:
             self._crop(n["hyper_dec"][2](h), yh, yw, out=cat[:, :, :arch.DMC_CH_Y])
         n["temporal"](ctx_t, out=cat[:, :, arch.DMC_CH_Y:])
-        p = cat
-        for blk in n["fusion"]:
-            p = blk(p)
-        return n["fusion_out"](p)
+        return n["fusion_out"](L.dcb_chain(n["fusion"], cat))
 
     def _spatial_prior(self, y_hat, params):
         n = self._layers
-        return n["spatial_out"](n["spatial"][1](n["spatial"][0](y_hat, params)))
+        return n["spatial_out"](L.dcb_chain(n["spatial"], y_hat, params))
 
     def _decoder(self, y_hat, ctx, q_decoder, out=None):
         n = self._layers
-        f = n["dec_conv1"][0](n["dec_up"](y_hat), ctx)
-        f = n["dec_conv1"][2](n["dec_conv1"][1](f))
+        f = L.dcb_chain(n["dec_conv1"], n["dec_up"](y_hat), ctx)
         return n["dec_conv2"](f, quant=q_decoder, out=out)
 
     def _recon(self, feature, q_recon):
         n = self._layers
-        o = n["recon"][2](n["recon"][1](n["recon"][0](feature)))
-        o = n["recon"][3](o, quant=q_recon)
+        o = L.dcb_chain(n["recon"], feature, quant=q_recon)
         return self._shuffle8_clamp(n["recon_head"](o))
 
     # ---- frame API
@@ -455,8 +448,7 @@ class DMC(CompressionModel):
             f = self._adapt(variant, ref_buf)
             x1, ctx_t = self._extractor_part1(f, q["q_feature"])
             ctx = self._extractor_part2(x1)
-            e = n["enc_conv2"][0](n["enc_conv1"](xin), ctx)
-            e = n["enc_conv3"](n["enc_conv2"][1](e), quant=q["q_encoder"])
+            e = L.dcb_chain(n["enc_conv2"] + [n["enc_conv3"]], n["enc_conv1"](xin), ctx, quant=q["q_encoder"])
             y = n["enc_down"](e)
             yh, yw = y.shape[0], y.shape[1]
             z = n["hyper_enc"][2](n["hyper_enc"][1](n["hyper_enc"][0](self._pad_for_y(y))))

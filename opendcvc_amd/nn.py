@@ -83,6 +83,7 @@ class DepthConvBlock:
         self.c_p = cpad(self.c, 64)
         self.cin_p = cpad(self.cin, 32) if self.has_adaptor else self.c_p
         self.dtype = dtype
+        self.shortcut = bool(shortcut)
         arrs = [wa, ba, w1, g(".dc.0.bias"), g(".dc.2.weight"), g(".dc.2.bias"), g(".dc.3.weight"),
                 g(".dc.3.bias"), g(".ffn.0.weight"), g(".ffn.0.bias"), g(".ffn.2.weight"), g(".ffn.2.bias")]
         h = ctypes.c_void_p()
@@ -97,9 +98,10 @@ class DepthConvBlock:
         except Exception:
             pass
 
-    def __call__(self, x0, x1=None, quant=None, out=None):
+    def __call__(self, x0, x1=None, quant=None, out=None, head_done=False, a_slot=0, next_block=None):
         """x = concat(x0, x1) along channels; quant: float32 device tensor [C] or None;
-        out: optional HWC view to write into (e.g. a slice of a concat buffer)."""
+        out: optional HWC view to write into (e.g. a slice of a concat buffer).
+        head_done / a_slot / next_block: see dcb_chain() (dcvc_dcb_forward_chained)."""
         L = _lib.lib()
         H, W, c0, ld0 = _geom(x0)
         c1, ld1 = 0, 0
@@ -116,9 +118,33 @@ class DepthConvBlock:
             raise DcvcError("dtype mismatch between block and tensors")
         nbytes = L.dcvc_dcb_scratch_bytes(self.h, H, W)
         scratch = Scratch.get(nbytes, x0.device)
-        check(L.dcvc_dcb_forward(self.h, _p(x0), ld0, c0, _p(x1), ld1, c1, H, W, _p(quant), _p(out), ldo,
-                                 _p(scratch), _stream()), "dcvc_dcb_forward")
+        check(L.dcvc_dcb_forward_chained(self.h, _p(x0), ld0, c0, _p(x1), ld1, c1, H, W, _p(quant), _p(out), ldo,
+                                         _p(scratch), _stream(), int(head_done), int(a_slot),
+                                         next_block.h if next_block is not None else None), "dcvc_dcb_forward")
         return out
+
+    def can_follow(self, prev, prev_quant):
+        """True if `prev` (run with quant step `prev_quant`) may compute this block's first conv in its epilogue"""
+        return (not self.has_adaptor and self.c_p == prev.c_p and self.dtype == prev.dtype and prev_quant is None
+                and not prev.shortcut)
+
+
+def dcb_chain(blocks, x0, x1=None, quant=None, out=None):
+    """A run of DepthConvBlocks feeding each other (nn.Sequential of DepthConvBlock in the reference models):
+    wherever allowed, block i computes block i+1's pointwise first conv + activation on its output tile while
+    that tile is still in LDS, so block i+1 starts at its depthwise stage (one launch and one activation read
+    less per block; results are bit-identical to calling the blocks one by one).  x1 goes to the first
+    block, quant / out to the last."""
+    x = x0
+    fused = False
+    for i, b in enumerate(blocks):
+        last = i + 1 == len(blocks)
+        qi = quant if last else None
+        nxt = None if last or not blocks[i + 1].can_follow(b, qi) else blocks[i + 1]
+        x = b(x, x1 if i == 0 else None, quant=qi, out=out if last else None, head_done=fused, a_slot=i & 1,
+              next_block=nxt)
+        fused = nxt is not None
+    return x
 
 
 class Conv2d:
