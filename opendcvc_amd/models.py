@@ -581,31 +581,21 @@ class DMCI(CompressionModel):
     def _enc(self, x, q):
         n = self._layers
         o = n["enc_1"](self._unshuffle8(x), quant=q)
-        for blk in n["enc_2"]:
-            o = blk(o)
-        return n["enc_down"](o)
+        return n["enc_down"](L.dcb_chain(n["enc_2"], o))
 
     def _dec(self, y_hat, q):
         n = self._layers
-        o = n["dec_up"](y_hat)
-        for blk in n["dec_1"][:-1]:
-            o = blk(o)
-        o = n["dec_1"][-1](o, quant=q)
+        o = L.dcb_chain(n["dec_1"], n["dec_up"](y_hat), quant=q)
         return self._shuffle8_clamp(n["dec_2"](o))
 
     def _prior_params(self, z_hat, yh, yw):
         n = self._layers
         p = n["hyper_dec"][2](n["hyper_dec"][1](n["hyper_dec"][0](z_hat)))
-        for blk in n["fusion"]:
-            p = blk(p)
-        return self._crop(n["fusion_out"](p), yh, yw)     # [yh, yw, 544]: q_enc q_dec | scales | means | pad
+        return self._crop(n["fusion_out"](L.dcb_chain(n["fusion"], p)), yh, yw)     # [yh, yw, 544]: q_enc q_dec | scales | means | pad
 
     def _spatial_prior(self, y_hat, common, step):
         n = self._layers
-        x = n["sp_adaptor"][step](y_hat, common)
-        for blk in n["spatial"]:
-            x = blk(x)
-        return n["spatial_out"](x)
+        return n["spatial_out"](L.dcb_chain([n["sp_adaptor"][step]] + n["spatial"], y_hat, common))
 
     def compress(self, x, qp):
         """image_model.py:143-185 + compress_prior_4x (common_model.py:206-256)"""
