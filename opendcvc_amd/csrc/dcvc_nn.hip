@@ -331,11 +331,8 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        float av[V], wv[V];
-                        unpack16<T>(*reinterpret_cast<const Vec16*>(bufV + ((my + ky) * HW_ + mx + kx) * lds_s + cs), av);
-                        unpack16<T>(wtap[ky * 3 + kx], wv);
-#pragma unroll
-                        for (int j = 0; j < V; ++j) s[j] = DCVC_FMAF(av[j], wv[j], s[j]);
+                        fma_vec16<T>(*reinterpret_cast<const Vec16*>(bufV + ((my + ky) * HW_ + mx + kx) * lds_s + cs),
+                                     wtap[ky * 3 + kx], s);
                     }
 #pragma unroll
                 for (int j = 0; j < V; ++j) s[j] = s[j] + bdv[j];

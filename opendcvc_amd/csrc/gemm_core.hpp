@@ -214,6 +214,29 @@ __device__ __forceinline__ void unpack16<float>(const Vec16& v, float (&f)[4])
     for (int j = 0; j < 4; ++j) f[j] = h[j];
 }
 
+// s[j] = fma(a[j], w[j], s[j]) over the kVec elements of two raw 16-byte vectors, fp32 accumulate.
+// fp16: v_fma_mix_f32 reads the halves straight out of the packed dwords (no conversions; hipcc otherwise
+// emits v_cvt_f32_f16 per element + v_pk_fma_f32); fp32: the explicit fmaf chain of the exact mode.
+template <typename T>
+__device__ __forceinline__ void fma_vec16(const Vec16& a, const Vec16& w, float (&s)[Traits<T>::kVec]);
+
+template <>
+__device__ __forceinline__ void fma_vec16<half_t>(const Vec16& a, const Vec16& w, float (&s)[8])
+{
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(s[2 * d]) : "v"(a[d]), "v"(w[d]));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(s[2 * d + 1]) : "v"(a[d]), "v"(w[d]));
+    }
+}
+template <>
+__device__ __forceinline__ void fma_vec16<float>(const Vec16& a, const Vec16& w, float (&s)[4])
+{
+    const floatx4 af = __builtin_bit_cast(floatx4, a), wf = __builtin_bit_cast(floatx4, w);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = DCVC_FMAF(af[j], wf[j], s[j]);
+}
+
 // store one 16-byte global vector worth of channels [c, c+kVec) of row `row` into an LDS A tile
 template <typename T>
 __device__ __forceinline__ void lds_store_vec(T* buf, int ld, int row, int c, const Vec16& v);

@@ -1,0 +1,130 @@
+// Developer micro-benchmark: do MFMA work of one wave and transcendental-heavy VALU work of ANOTHER wave on the same
+// SIMD overlap?  One 8-wave workgroup per CU (waves w and w+4 share a SIMD); waves 0-3 run an MFMA chain on
+// registers, waves 4-7 evaluate the fp16-mode gate u / (1 + 2^u).  Modes: MFMA only, VALU only, both.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/coissue_mb.hip -o tools/coissue_mb
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+template <int SHAPE>   // 0: 16x16x32, 1: 32x32x16
+__global__ __launch_bounds__(512, 1) void k(float* out, int n_mfma, int n_valu, int mode)
+{
+    const int wave = threadIdx.x >> 6;
+    float s = 0;
+    if (wave < 4) {
+        if (mode == 1) return;
+        half8 a, b;
+        for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(threadIdx.x * 0.001f + j); b[j] = (_Float16)(j * 0.01f); }
+        if (SHAPE == 0) {
+            floatx4 acc[8];
+            for (int i = 0; i < 8; ++i) acc[i] = floatx4{0, 0, 0, 0};
+            for (int it = 0; it < n_mfma; ++it)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i], 0, 0, 0);
+            for (int i = 0; i < 8; ++i) s += acc[i][0];
+        } else {
+            floatx16 acc[4];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 16; ++j) acc[i][j] = 0;
+            for (int it = 0; it < n_mfma; ++it)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) s += acc[i][0];
+        }
+    } else {
+        if (mode == 0) return;
+        float u[16];
+        for (int j = 0; j < 16; ++j) u[j] = threadIdx.x * 0.01f + j * 0.1f - 3.f;
+        for (int it = 0; it < n_valu; ++it)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) u[j] = u[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u[j])) + 0.25f;
+        for (int j = 0; j < 16; ++j) s += u[j];
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
+// one wave per SIMD, MFMA and gates interleaved in ONE instruction stream: G gates per 8 MFMAs
+template <int G>
+__global__ __launch_bounds__(256, 1) void k1(float* out, int n)
+{
+    half8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(threadIdx.x * 0.001f + j); b[j] = (_Float16)(j * 0.01f); }
+    floatx4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = floatx4{0, 0, 0, 0};
+    float u[G > 0 ? G : 1];
+    for (int j = 0; j < G; ++j) u[j] = threadIdx.x * 0.01f + j * 0.1f - 3.f;
+    for (int it = 0; it < n; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i], 0, 0, 0);
+            if (G >= 8 || i < G) {
+#pragma unroll
+                for (int j = i * G / 8; j < (i + 1) * G / 8 + (G < 8 ? 1 : 0) && j < G; ++j)
+                    u[j] = u[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u[j])) + 0.25f;
+            }
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += acc[i][0];
+    for (int j = 0; j < G; ++j) s += u[j];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int G>
+void run1(float* out)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float ms = 0;
+    for (int it = 0; it < 2; ++it) {
+        hipEventRecord(e0);
+        k1<G><<<256, 256>>>(out, 4000);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    printf("same wave, %2d gates per 8 MFMAs: %.1f us  (%.1f cycles @2.4GHz per 8-MFMA group; MFMA pipe alone 128, gates alone %d)\n", G,
+           ms * 1e3f, ms * 1e-3 * 2.4e9 / 4000, G * 24);
+}
+
+template <int SHAPE>
+float run(float* out, int nm, int nv, int mode)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float ms = 0;
+    for (int it = 0; it < 2; ++it) {
+        hipEventRecord(e0);
+        k<SHAPE><<<256, 512>>>(out, nm, nv, mode);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    return ms * 1e3f;
+}
+
+int main()
+{
+    float* out;
+    hipMalloc(&out, 256 * 512 * 4);
+    const int nm = 4000;          // x8 MFMAs of 16 cycles (or x4 of 32) = 512 K MFMA-pipe cycles per wave
+    for (int nv : {1000, 2000, 4000}) {   // x16 gates x 4 instr
+        for (int shape = 0; shape < 2; ++shape) {
+            float t[3];
+            for (int mode = 0; mode < 3; ++mode) t[mode] = shape == 0 ? run<0>(out, nm, nv, mode) : run<1>(out, nm, nv, mode);
+            printf("%s  n_valu=%d: MFMA alone %.1f us, VALU alone %.1f us, both %.1f us (sum %.1f, max %.1f)\n",
+                   shape == 0 ? "16x16x32" : "32x32x16", nv, t[0], t[1], t[2], t[0] + t[1], t[0] > t[1] ? t[0] : t[1]);
+        }
+    }
+    run1<0>(out);
+    run1<1>(out);
+    run1<2>(out);
+    run1<4>(out);
+    run1<8>(out);
+    run1<16>(out);
+    return 0;
+}
