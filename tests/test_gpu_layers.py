@@ -115,6 +115,34 @@ def test_depth_conv_block_large_map_fp16(c):
     compare(got[:, :, :c], ref, torch.float16, f"dcb large map c={c}")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("c,hw", [(256, (21, 19)), (128, (9, 33)), (368, (12, 11)), (320, (101, 123))])
+def test_chained_blocks_equal_separate_calls(c, hw, dtype):
+    """dcb_chain (the next block's first conv computed in the previous block's epilogue) is bit-identical to
+    calling the blocks one by one, in both modes; a block with a quant step or a different width ends a chain."""
+    from opendcvc_amd import nn
+    from opendcvc_amd._lib import DcvcError
+    if dtype == torch.float32 and hw[0] > 50:
+        pytest.skip("large map only needed for the fp16 64-pixel kernels")
+    H, W = hw
+    rng = _rng(400 + c)
+    blocks = [nn.DepthConvBlock(make_dcb_weights(rng, "m", 2 * c if i == 0 else c, c, i == 0), "m", dtype) for i in range(4)]
+    x0 = to_dev(rng.standard_normal((H, W, 2 * c)).astype(np.float32), blocks[0].cin_p, dtype)
+    q = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)).cuda()
+    want = blocks[0](x0)
+    for i, b in enumerate(blocks[1:]):
+        want = b(want, quant=q if i == 2 else None)
+    got = nn.dcb_chain(blocks, x0, quant=q)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    # a quant step in the middle: the follower must not be fused (the library refuses it if asked directly)
+    with pytest.raises(DcvcError):
+        blocks[1](want, quant=q, next_block=blocks[2])
+    other = nn.DepthConvBlock(make_dcb_weights(rng, "m", 64, 64, False), "m", dtype)
+    assert not other.can_follow(blocks[1], None) and blocks[2].can_follow(blocks[1], None)
+    assert not blocks[2].can_follow(blocks[1], q)
+
+
 def test_dcb_writes_into_concat_slice():
     from opendcvc_amd import nn
     rng = _rng(5)
