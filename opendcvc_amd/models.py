@@ -308,6 +308,7 @@ class DMC(CompressionModel):
         self.dpb = []
         self.max_dpb_size = 1
         self.curr_poc = 0
+        self._ahead = None       # (height, width, x1, ctx): feature extractor of the NEXT frame, run ahead
 
     def _build_layers(self, sd, dt):
         D, C2, R = L.DepthConvBlock, L.Conv2d, L.ResidualBlockWithStride2
@@ -337,10 +338,12 @@ class DMC(CompressionModel):
 
     # ---- DPB (video_model.py:253-277)
     def reset_ref_feature(self):
+        self._ahead = None
         if len(self.dpb) > 0:
             self.dpb[0].feature = None
 
     def add_ref_frame(self, feature=None, frame=None, increase_poc=True):
+        self._ahead = None           # a context computed ahead belongs to the previous reference
         ref = RefFrame()
         ref.poc = self.curr_poc
         ref.frame = frame
@@ -352,6 +355,7 @@ class DMC(CompressionModel):
             self.curr_poc += 1
 
     def clear_dpb(self):
+        self._ahead = None
         self.dpb.clear()
 
     def set_curr_poc(self, poc):
@@ -368,13 +372,15 @@ class DMC(CompressionModel):
 
     # ---- sub-networks
     def _extractor_part1(self, f, q_feature):
-        n = self._layers
-        x1 = L.dcb_chain(n["fe1"], f)
+        x1 = L.dcb_chain(self._layers["fe1"], f)
+        return x1, self._scaled_context(x1, q_feature)
+
+    def _scaled_context(self, x1, q_feature):
         ctx_t = torch.empty_like(x1)
         H, W, C, ld = L._geom(x1)
         check(_lib.lib().dcvc_scale_channels(L.dtype_code(x1.dtype), L._p(x1), ld, L._p(q_feature), H * W, C,
                                              L._p(ctx_t), C, self._stream()), "scale_channels")
-        return x1, ctx_t
+        return ctx_t
 
     def _extractor_part2(self, x1):
         return L.dcb_chain(self._layers["fe2"], x1)
@@ -443,11 +449,18 @@ class DMC(CompressionModel):
         variant, ref_buf = self._stage_reference(dtype, device)
         fbuf = self._feature_buf((H // 8, W // 8, arch.DMC_CH_D), dtype, device)
         key = (variant, H, W)
+        # The feature extractor depends on the reference feature only (not on this frame, not on qp): the previous
+        # compress() has already run it for us while its own entropy coding kept the host busy.
+        ahead = self._ahead if (variant == "p" and self._ahead is not None and self._ahead[:2] == (H, W)) else None
 
         def front():
-            f = self._adapt(variant, ref_buf)
-            x1, ctx_t = self._extractor_part1(f, q["q_feature"])
-            ctx = self._extractor_part2(x1)
+            if ahead is not None:
+                x1, ctx = ahead[2], ahead[3]
+                ctx_t = self._scaled_context(x1, q["q_feature"])
+            else:
+                f = self._adapt(variant, ref_buf)
+                x1, ctx_t = self._extractor_part1(f, q["q_feature"])
+                ctx = self._extractor_part2(x1)
             e = L.dcb_chain(n["enc_conv2"] + [n["enc_conv3"]], n["enc_conv1"](xin), ctx, quant=q["q_encoder"])
             y = n["enc_down"](e)
             yh, yw = y.shape[0], y.shape[1]
@@ -465,11 +478,18 @@ class DMC(CompressionModel):
             hp = self._d2h("packed", packed)
             return y_hat, ctx, hz, hp, z8.numel(), nsym, (z.shape[0], z.shape[1])
 
-        y_hat, ctx, hz, hp, nz, nsym, (zh, zw) = self._graphs.run(("enc_front",) + key, front)
+        y_hat, ctx, hz, hp, nz, nsym, (zh, zw) = self._graphs.run(
+            ("enc_front_ahead" if ahead is not None else "enc_front",) + key, front)
         ready = torch.cuda.Event()
         ready.record()
         # the decoder keeps the GPU busy while the host codes
         self._graphs.run(("enc_back",) + key, lambda: self._decoder(y_hat, ctx, q["q_decoder"], out=fbuf))
+        nxt = None
+        if self._graphs.enabled:     # next frame's extractor, behind the decoder and under the host coder below
+            def extractor_ahead():
+                x1n = L.dcb_chain(self._layers["fe1"], self._layers["fa_p"](fbuf))
+                return x1n, self._extractor_part2(x1n)
+            nxt = (H, W) + tuple(self._graphs.run(("enc_ahead", H, W), extractor_ahead))
 
         ready.synchronize()
         ec = self.entropy_coder
@@ -483,6 +503,7 @@ class DMC(CompressionModel):
         # no device synchronisation here (the reference has none either): the tail of the decoder stays in
         # flight on this stream and overlaps the caller's next host work; callers that time a frame sync.
         self.add_ref_frame(fbuf, None)
+        self._ahead = nxt
         return {"bit_stream": bit_stream}
 
     def decompress(self, bit_stream, sps, qp):
