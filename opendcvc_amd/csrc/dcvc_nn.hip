@@ -577,6 +577,8 @@ struct ConvParams {
     int epi;
     void* out;
     long ldo;
+    int halo;      // KH x KW > 1: the input tile + halo is staged once and all taps read it (else: one tap at a time)
+    int split_n;   // the passes over the output channels are spread over blockIdx.y (small maps) instead of looped
 };
 
 template <typename T, int MT, int NTW>
@@ -609,11 +611,28 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvParams p)
         }
     };
 
+    const int HT_W = (TW - 1) * p.stride + p.KW, HT_H = (TH - 1) * p.stride + p.KH;
+    const T* xrow[MT];
     if (taps == 1) {
         stage(0);
         __syncthreads();
+    } else if (p.halo) {
+        const int iy0 = ty0 * p.stride - p.pad, ix0 = tx0 * p.stride - p.pad;
+        for (int it = tid; it < HT_H * HT_W * G; it += NTHREADS) {
+            const int hp = it / G, c = (it - hp * G) * TR::kVec;
+            const int iy = iy0 + hp / HT_W, ix = ix0 + hp % HT_W;
+            const bool valid = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            lds_store_vec<T>(bufX, ldx, hp, c, load_src<T>(p.src, (long)iy * p.W + ix, c, valid));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int pix = m * 16 + (lane & 15);
+            xrow[m] = bufX + ((pix / TW) * p.stride * HT_W + (pix % TW) * p.stride) * ldx + (lane >> 4) * 8;
+        }
     }
-    for (int pass = 0; pass < passes; ++pass) {
+    const int pass_lo = p.split_n ? (int)blockIdx.y : 0, pass_hi = p.split_n ? (int)blockIdx.y + 1 : passes;
+    for (int pass = pass_lo; pass < pass_hi; ++pass) {
         int tiles[NTW];
         bool tvalid[NTW];
 #pragma unroll
@@ -626,6 +645,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvParams p)
         zero_acc(acc);
         if (taps == 1) {
             gemm_acc<T, MT, NTW, PF>(acc, bufX, ldx, kgin, reinterpret_cast<const frag_t*>(p.w), kgin, 0, tiles, lane);
+        } else if (p.halo) {
+            gemm_taps<T, MT, NTW, PF>(acc, xrow, ldx, taps, p.KW, HT_W, kgin, reinterpret_cast<const frag_t*>(p.w), tiles, lane);
         } else {
             for (int tap = 0; tap < taps; ++tap) {
                 __syncthreads();
@@ -951,10 +972,20 @@ template <typename T, int MT, int NTW>
 int launch_conv(const dcvc_conv* h, const ConvParams& cp, hipStream_t st)
 {
     const int grid = ((cp.Ho + Tile<MT>::TH - 1) / Tile<MT>::TH) * ((cp.Wo + Tile<MT>::TW - 1) / Tile<MT>::TW);
-    const size_t lds = (size_t)Tile<MT>::M * (cp.src.c0 + cp.src.c1 + Traits<T>::kPad) * sizeof(T);
+    const size_t row = (size_t)(cp.src.c0 + cp.src.c1 + Traits<T>::kPad) * sizeof(T);
+    size_t lds = (size_t)Tile<MT>::M * row;
+    ConvParams p = cp;
+    if (cp.KH * cp.KW > 1) {   // whole input tile + halo in LDS if it fits next to a second workgroup
+        const size_t halo = (size_t)((Tile<MT>::TH - 1) * cp.stride + cp.KH) * ((Tile<MT>::TW - 1) * cp.stride + cp.KW) * row;
+        p.halo = halo <= 96 * 1024;
+        if (p.halo) lds = halo;
+    }
+    // maps that do not fill the GPU with one workgroup per pixel tile: one workgroup per (tile, channel pass)
+    const int passes = (cp.N / 16 + NWAVE * NTW - 1) / (NWAVE * NTW);
+    p.split_n = passes > 1 && grid < 400;
     int rc = set_lds(conv_kernel<T, MT, NTW>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((conv_kernel<T, MT, NTW>), dim3(grid), dim3(NTHREADS), lds, st, cp);
+    hipLaunchKernelGGL((conv_kernel<T, MT, NTW>), dim3(grid, p.split_n ? passes : 1), dim3(NTHREADS), lds, st, p);
     DCVC_LAUNCH_CHECK();
     (void)h;
     return 0;

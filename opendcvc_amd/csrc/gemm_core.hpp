@@ -173,6 +173,60 @@ __device__ __forceinline__ void gemm_run(floatx4 (&acc)[MT][NT], const T* X, int
         if (kfull + s < kgs) step(kfull + s, s);
 }
 
+// Implicit-GEMM form for KH x KW convolutions: the reduction runs over (tap, cin) in one uninterrupted
+// weight pipeline; the pixel fragment of tap (ky, kx) is read from a halo tile in LDS at a per-tap row offset
+// (xrow[m] points at the lane's pixel row for tap (0, 0); rows of the halo tile are HT_W pixels wide).
+// Same accumulation order as staging one tap at a time (taps outer, channels ascending).
+template <typename T, int MT, int NT, int PF>
+__device__ __forceinline__ void gemm_taps(floatx4 (&acc)[MT][NT], const T* const (&xrow)[MT], int ldx, int taps, int KW,
+                                          int HT_W, int kgin, const typename Traits<T>::frag_t* __restrict__ Wp,
+                                          const int (&tiles)[NT], int lane)
+{
+    using frag_t = typename Traits<T>::frag_t;
+    const int kgs = taps * kgin;
+    WPre<T, NT, PF> pre;
+    gemm_prefetch<T, NT, PF>(pre, kgs, Wp, kgs, 0, tiles, lane);
+    const frag_t* w_base[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) w_base[i] = Wp + (size_t)tiles[i] * kgs * 64 + lane;
+    int kk = 0, kx = 0, ky = 0;
+    auto step = [&](int g, int s) __attribute__((always_inline)) {
+        const int off = (ky * HT_W + kx) * ldx + kk * KG;
+        if (++kk == kgin) {
+            kk = 0;
+            if (++kx == KW) {
+                kx = 0;
+                ++ky;
+            }
+        }
+        frag_t x[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) x[m] = *reinterpret_cast<const frag_t*>(xrow[m] + off);
+        const int gn = (g + PF < kgs) ? g + PF : kgs - 1;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][i] = Traits<T>::mma(pre.w[s][i], x[m], acc[m][i]);
+            pre.w[s][i] = w_base[i][(size_t)gn * 64];
+        }
+        constexpr int kMfmaPerMma = sizeof(T) == 2 ? 1 : 8, kVecPerFrag = sizeof(T) == 2 ? 1 : 2;
+        __builtin_amdgcn_sched_group_barrier(0x100, MT * kVecPerFrag, 0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * kMfmaPerMma, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, kVecPerFrag, 0);
+        }
+    };
+    const int kfull = (kgs / PF) * PF;
+    for (int g0 = 0; g0 < kfull; g0 += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) step(g0 + s, s);
+    }
+#pragma unroll
+    for (int s = 0; s < PF - 1; ++s)
+        if (kfull + s < kgs) step(kfull + s, s);
+}
+
 template <typename T, int MT, int NT, int PF>
 __device__ __forceinline__ void gemm_acc(floatx4 (&acc)[MT][NT], const T* X, int ldx, int kgs,
                                          const typename Traits<T>::frag_t* __restrict__ Wp,
