@@ -848,9 +848,20 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         // `a` was written by the previous block's tail
     } else if (h->adapt) {
         const size_t lds = head_lds<T, MT>(kin, C, true);
-        int rc = set_lds(dcb_head_kernel<T, MT, NTW, true>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((dcb_head_kernel<T, MT, NTW, true>), dim3(grid), dim3(NTHREADS), lds, st, hp);
+        if (MT == 4 && lds > 80 * 1024) {
+            // a 64-pixel tile of a wide two-source input leaves room for one workgroup per CU (two rounds over
+            // a 136x240 map); 32-pixel tiles fit three per CU (97 -> 88 us for head + tail at 256+256 -> 256).
+            // Head and tail tile shapes are independent.
+            const int grid2 = ((H + Tile<2>::TH - 1) / Tile<2>::TH) * ((W + Tile<2>::TW - 1) / Tile<2>::TW);
+            const size_t lds2 = head_lds<T, 2>(kin, C, true);
+            int rc = set_lds(dcb_head_kernel<T, 2, NTW, true>, lds2);
+            if (rc) return rc;
+            hipLaunchKernelGGL((dcb_head_kernel<T, 2, NTW, true>), dim3(grid2), dim3(NTHREADS), lds2, st, hp);
+        } else {
+            int rc = set_lds(dcb_head_kernel<T, MT, NTW, true>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((dcb_head_kernel<T, MT, NTW, true>), dim3(grid), dim3(NTHREADS), lds, st, hp);
+        }
     } else {
         const size_t lds = head_lds<T, MT>(kin, C, false);
         int rc = set_lds(dcb_head_kernel<T, MT, NTW, false>, lds);

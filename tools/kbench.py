@@ -37,7 +37,7 @@ def run(C, H, W, dtype=torch.float16, iters=30):
     flop = 2.0 * H * W * (7 * C * C + 9 * C)
     print(f"C={C} {H}x{W} {dtype}: head {head.value*1e3:.1f} us  tail {tail.value*1e3:.1f} us  tail {flop/tail.value/1e9:.1f} TFLOP/s  ablate={os.environ.get('DCVC_ABLATE','0')}", flush=True)
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "conv"):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("conv", "adapt")):
     shapes = [(256, 136, 240), (256, 68, 120), (384, 68, 120), (128, 17, 30), (320, 136, 240)]
     for C, H, W in shapes if len(sys.argv) < 2 else [tuple(int(v) for v in sys.argv[1:4])]:
         run(C, H, W)
@@ -72,3 +72,27 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "conv":
                  (192, 256, 1, 1, 0, 0, 136, 240), (320, 192, 1, 1, 0, 0, 136, 240), (128, 512, 1, 1, 0, 2, 17, 30),
                  (128, 128, 2, 2, 0, 0, 68, 120)]:
         run_conv(*args)
+
+
+def run_adapt(cin0, cin1, C, H, W, dtype=torch.float16, iters=30):
+    """two-source DepthConvBlock with adaptor (e.g. encoder.conv2.0: features | context)"""
+    rng = np.random.default_rng(0)
+    sd = make_dcb_weights(rng, "m", cin0 + cin1, C, True)
+    blk = L.DepthConvBlock(sd, "m", dtype)
+    x0 = (torch.randn((H, W, cin0), device="cuda") * 0.5).to(dtype)
+    x1 = (torch.randn((H, W, cin1), device="cuda") * 0.5).to(dtype)
+    out = blk(x0, x1)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        blk(x0, x1, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"adaptor block {cin0}+{cin1}->{C} {H}x{W}: {e0.elapsed_time(e1) / iters * 1e3:.1f} us (head + tail)", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "adapt":
+    run_adapt(256, 256, 256, 136, 240)
+    run_adapt(256, 256, 320, 136, 240)
+    run_adapt(128, 384, 384, 68, 120)
