@@ -581,7 +581,9 @@ struct ConvParams {
     int split_n;   // the passes over the output channels are spread over blockIdx.y (small maps) instead of looped
 };
 
-template <typename T, int MT, int NTW>
+// HALO: KH x KW > 1 with the input tile + halo staged once (gemm_taps); a separate instantiation so that the 1x1
+// kernels do not carry its registers (they dropped from two waves per SIMD to one when it was a runtime switch).
+template <typename T, int MT, int NTW, bool HALO>
 __global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvParams p)
 {
     using TR = Traits<T>;
@@ -611,18 +613,31 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvParams p)
         }
     };
 
-    const int HT_W = (TW - 1) * p.stride + p.KW, HT_H = (TH - 1) * p.stride + p.KH;
-    const T* xrow[MT];
+    [[maybe_unused]] const int HT_W = (TW - 1) * p.stride + p.KW, HT_H = (TH - 1) * p.stride + p.KH;
+    [[maybe_unused]] const T* xrow[MT];
     if (taps == 1) {
         stage(0);
         __syncthreads();
-    } else if (p.halo) {
+    } else if constexpr (HALO) {
         const int iy0 = ty0 * p.stride - p.pad, ix0 = tx0 * p.stride - p.pad;
-        for (int it = tid; it < HT_H * HT_W * G; it += NTHREADS) {
-            const int hp = it / G, c = (it - hp * G) * TR::kVec;
-            const int iy = iy0 + hp / HT_W, ix = ix0 + hp % HT_W;
-            const bool valid = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            lds_store_vec<T>(bufX, ldx, hp, c, load_src<T>(p.src, (long)iy * p.W + ix, c, valid));
+        const int total = HT_H * HT_W * G;
+        constexpr int U = 8;               // loads in flight per thread (the tile is up to ~5 000 vectors)
+        for (int it0 = tid; it0 < total; it0 += U * NTHREADS) {
+            Vec16 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int it = it0 + u * NTHREADS;
+                const int hp = it / G, c = (it - hp * G) * TR::kVec;
+                const int iy = iy0 + hp / HT_W, ix = ix0 + hp % HT_W;
+                const bool valid = it < total && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                v[u] = load_src<T>(p.src, (long)iy * p.W + ix, c, valid);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int it = it0 + u * NTHREADS;
+                const int hp = it / G, c = (it - hp * G) * TR::kVec;
+                if (it < total) lds_store_vec<T>(bufX, ldx, hp, c, v[u]);
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -645,7 +660,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvParams p)
         zero_acc(acc);
         if (taps == 1) {
             gemm_acc<T, MT, NTW, PF>(acc, bufX, ldx, kgin, reinterpret_cast<const frag_t*>(p.w), kgin, 0, tiles, lane);
-        } else if (p.halo) {
+        } else if constexpr (HALO) {
             gemm_taps<T, MT, NTW, PF>(acc, xrow, ldx, taps, p.KW, HT_W, kgin, reinterpret_cast<const frag_t*>(p.w), tiles, lane);
         } else {
             for (int tap = 0; tap < taps; ++tap) {
@@ -988,15 +1003,24 @@ int launch_conv(const dcvc_conv* h, const ConvParams& cp, hipStream_t st)
     ConvParams p = cp;
     if (cp.KH * cp.KW > 1) {   // whole input tile + halo in LDS if it fits next to a second workgroup
         const size_t halo = (size_t)((Tile<MT>::TH - 1) * cp.stride + cp.KH) * ((Tile<MT>::TW - 1) * cp.stride + cp.KW) * row;
-        p.halo = halo <= 96 * 1024;
+        // (stride 2 keeps the tap-at-a-time path: rows two pixels apart collide in the LDS banks - measured 37 -> 52 us
+        //  for the 3x3 s2 256 -> 128 conv with the halo tile)
+        p.halo = cp.stride == 1 && halo <= 96 * 1024;
         if (p.halo) lds = halo;
     }
     // maps that do not fill the GPU with one workgroup per pixel tile: one workgroup per (tile, channel pass)
     const int passes = (cp.N / 16 + NWAVE * NTW - 1) / (NWAVE * NTW);
     p.split_n = passes > 1 && grid < 400;
-    int rc = set_lds(conv_kernel<T, MT, NTW>, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL((conv_kernel<T, MT, NTW>), dim3(grid, p.split_n ? passes : 1), dim3(NTHREADS), lds, st, p);
+    const dim3 g(grid, p.split_n ? passes : 1);
+    if (p.halo) {
+        int rc = set_lds(conv_kernel<T, MT, NTW, true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((conv_kernel<T, MT, NTW, true>), g, dim3(NTHREADS), lds, st, p);
+    } else {
+        int rc = set_lds(conv_kernel<T, MT, NTW, false>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((conv_kernel<T, MT, NTW, false>), g, dim3(NTHREADS), lds, st, p);
+    }
     DCVC_LAUNCH_CHECK();
     (void)h;
     return 0;
