@@ -73,6 +73,7 @@ class EncodeDecodePipeline:
     def __init__(self, encoder, decoder, device, depth=2):
         import torch
         self.encoder, self.decoder, self.device, self.depth = encoder, decoder, device, depth
+        # (a high-priority decoder stream was measured: no difference - the pair is GPU-bound either way)
         self.enc_stream, self.dec_stream = torch.cuda.Stream(device), torch.cuda.Stream(device)
         self._warm = 0
 
