@@ -120,3 +120,29 @@ def test_two_stage_pipeline_equals_sequential(dtype):
         assert (gp.is_i, gp.qp, gp.use_ada_i) == (wp.is_i, wp.qp, wp.use_ada_i)
         assert gp.bit_stream == wp.bit_stream, f"frame {fi}: packet differs"
         assert np.array_equal(gx, wx), f"frame {fi}: reconstruction differs"
+
+
+def test_graph_replay_equals_plain_launches():
+    """Captured runs (HIP graphs) vs the same kernels launched one by one: same packets and reconstructions,
+    including the encoder's run-ahead of the next frame's feature extractor (graphs only)."""
+    from opendcvc_amd.pipeline import SequenceDecoder, SequenceEncoder
+    h, w, n = 96, 160, 6
+    frames = [torch.from_numpy(weights.synthetic_frame_yuv444(h, w, fi, 5)).to("cuda", torch.float16) for fi in range(n)]
+    results = []
+    for graphs in (True, False):
+        (ie, pe), (idc, pdc) = hip_codecs(1234, 0.12, torch.float16), hip_codecs(1234, 0.12, torch.float16)
+        for m in (ie, pe, idc, pdc):
+            m.set_use_two_entropy_coders(False)
+            m._graphs.enabled = graphs
+        enc = SequenceEncoder(ie, pe, 24, intra_period=-1, reset_interval=4)
+        dec = SequenceDecoder(idc, pdc, h, w, False)
+        out = []
+        for x in frames:
+            pkt = enc.encode(x)
+            out.append((pkt.bit_stream, dec.decode(pkt).float().cpu().numpy()))
+        if graphs:
+            assert pe._graphs.variants("enc_front_ahead") == {"p"} and pdc._graphs.variants("dec_4") == {"i", "p"}
+        results.append(out)
+    for fi, ((b0, x0), (b1, x1)) in enumerate(zip(*results)):
+        assert b0 == b1, f"frame {fi}: packet differs between graph replay and plain launches"
+        assert np.array_equal(x0, x1), f"frame {fi}: reconstruction differs"
