@@ -1,0 +1,272 @@
+"""One rate point (or a qp sweep) over one planar 8-bit YUV 4:2:0 sequence on the HIP path, logged in the
+reference's JSON schema - SURVEY.md section 8(f)-3.
+
+Restates (no code shared) the behaviour of the reference harness:
+  test_video.py:130-353   run_one_point_with_stream: encode every frame into the NAL container, write the
+                          .bin, decode it back, distortion per decoded frame, timing, JSON log
+  test_video.py:94-127    get_distortion (YUV 4:2:0: per-plane PSNR, combined (6 Y + U + V) / 8)
+  test_video.py:448-463   the qp points of a sweep
+  src/utils/metrics.py:81-96   calc_psnr
+  src/utils/common.py:63-177   generate_log_json
+Dataset manifests, PNG sources, MS-SSIM and the multi-process sequence pool are out of scope (SURVEY section 2,
+rows 11-15); the codec calls are the drop-in DMCI / DMC of opendcvc_amd.models.
+"""
+import io
+import json
+import math
+import time
+
+import numpy as np
+
+from .bitstream import StreamReader, StreamWriter
+from .pipeline import (SequenceDecoder, SequenceEncoder, load_yuv420_frame, store_yuv420_frame,
+                       use_two_entropy_coders)
+
+
+# ---------------------------------------------------------------------------------- metrics / log
+def psnr_from_mse(mse, data_range=255.0):
+    """metrics.py:81-96: -999.9 for nan/inf, 999.9 below 1e-10, capped at 99.9"""
+    if math.isnan(mse) or math.isinf(mse):
+        return -999.9
+    psnr = 10.0 * math.log10(data_range * data_range / mse) if mse > 1e-10 else 999.9
+    return min(psnr, 99.9)
+
+
+def calc_psnr(a, b, data_range=255.0):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return psnr_from_mse(float(np.mean(np.square(a - b))), data_range)
+
+
+def yuv420_distortion(x_hat, y, u, v):
+    """test_video.py:94-111 on the device: x_hat [1,3,H',W'] (model dtype, cropped here), y/u/v uint8 planes.
+    The planes of the reconstruction are the clamped, NOT rounded, values (chroma = 2x2 mean), in the
+    reconstruction's own dtype like the reference's tensors; squared errors are summed in float64."""
+    import torch
+    H, W = y.shape
+    x = x_hat[:, :, :H, :W]
+    y_rec = torch.clamp(x[:, :1] * 255, 0, 255)
+    uv_rec = torch.clamp(torch.nn.functional.avg_pool2d(x[:, 1:], 2) * 255, 0, 255)
+    out = []
+    for rec, src in ((y_rec[0, 0], y), (uv_rec[0, 0], u), (uv_rec[0, 1], v)):
+        out.append(psnr_from_mse(float(torch.mean(torch.square(rec.double() - src.double())))))
+    return [(6 * out[0] + out[1] + out[2]) / 8] + out
+
+
+def summarize(frame_pixel_num, test_time, frame_types, bits, psnrs, ssims, verbose=False,
+              avg_encoding_time=None, avg_decoding_time=None):
+    """The reference's per-sequence log (common.py:63-177): averages over I frames (type 0), P frames and
+    all frames of bpp / PSNR / MS-SSIM (plus the Y, U, V components when 4-tuples are given), optional
+    per-frame lists, timings.  Same keys, same insertion order."""
+    n = len(frame_types)
+    P = np.asarray(psnrs, np.float64).reshape(n, -1)
+    S = np.asarray(ssims, np.float64).reshape(n, -1)
+    B = np.asarray(bits, np.float64)
+    T = np.asarray(frame_types)
+    yuv = P.shape[1] > 1
+    if yuv and not (P.shape[1] == 4 and S.shape[1] == 4):
+        raise ValueError("per-frame metrics must be 1 value or (all, y, u, v)")
+    comp = (("", 0), ("_y", 1), ("_u", 2), ("_v", 3)) if yuv else (("", 0),)
+    is_i = T == 0
+    log = {"frame_pixel_num": frame_pixel_num, "i_frame_num": int(is_i.sum()), "p_frame_num": int((~is_i).sum())}
+
+    def block(tag, sel, count):
+        log[f"ave_{tag}_frame_bpp"] = float(B[sel].sum() / count / frame_pixel_num) if count else 0
+        for kind, M in (("psnr", P), ("msssim", S)):
+            log[f"ave_{tag}_frame_{kind}"] = float(M[sel, 0].sum() / count) if count else 0
+        for kind, M in (("psnr", P), ("msssim", S)):
+            for suffix, k in comp[1:]:
+                log[f"ave_{tag}_frame_{kind}{suffix}"] = float(M[sel, k].sum() / count) if count else 0
+
+    if log["i_frame_num"] == 0:
+        raise ZeroDivisionError("a sequence log needs at least one I frame")
+    block("i", is_i, log["i_frame_num"])
+    if verbose:
+        log["frame_bpp"] = list(B / frame_pixel_num)
+        log["frame_psnr"] = [float(v) for v in P[:, 0]]
+        log["frame_msssim"] = [float(v) for v in S[:, 0]]
+        log["frame_type"] = list(frame_types)
+        for kind, M in (("psnr", P), ("msssim", S)):
+            for suffix, k in comp[1:]:
+                log[f"frame_{kind}{suffix}"] = [float(v) for v in M[:, k]]
+    log["test_time"] = test_time
+    block("p", ~is_i, log["p_frame_num"])
+    log["ave_all_frame_bpp"] = float(B.sum() / (n * frame_pixel_num))
+    log["ave_all_frame_psnr"] = float(P[:, 0].sum() / n)
+    log["ave_all_frame_msssim"] = float(S[:, 0].sum() / n)
+    if avg_encoding_time is not None and avg_decoding_time is not None:
+        log["avg_frame_encoding_time"] = avg_encoding_time
+        log["avg_frame_decoding_time"] = avg_decoding_time
+    for kind, M in (("psnr", P), ("msssim", S)):
+        for suffix, k in comp[1:]:
+            log[f"ave_all_frame_{kind}{suffix}"] = float(M[:, k].sum() / n)
+    return log
+
+
+def sweep_qps(rate_num, qp_num=64):
+    """test_video.py:452-455: rate_num points spread over the qp range, rounded half up"""
+    if not 2 <= rate_num <= qp_num:
+        raise ValueError("rate_num must be in [2, qp_num]")
+    return [int(i + 0.5) for i in np.linspace(0, qp_num - 1, num=rate_num)]
+
+
+# ---------------------------------------------------------------------------------- sequence I/O
+class YUV420FileReader:
+    """planar 8-bit 4:2:0 (video_reader.py:50-90): Y (H x W), U, V (H/2 x W/2) per frame"""
+
+    def __init__(self, path, width, height):
+        self.f = open(path, "rb")
+        self.w, self.h = width, height
+
+    def read(self):
+        ys, cs = self.w * self.h, (self.w // 2) * (self.h // 2)
+        buf = self.f.read(ys + 2 * cs)
+        if len(buf) < ys + 2 * cs:
+            raise EOFError("YUV file ended")
+        a = np.frombuffer(buf, np.uint8)
+        return (a[:ys].reshape(self.h, self.w), a[ys:ys + cs].reshape(self.h // 2, self.w // 2),
+                a[ys + cs:].reshape(self.h // 2, self.w // 2))
+
+    def close(self):
+        self.f.close()
+
+
+def _to_device(planes, device):
+    import torch
+    return [torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in planes]
+
+
+# ---------------------------------------------------------------------------------- one rate point
+def run_one_point(i_net, p_net, src_path, width, height, frame_num, qp_i, qp_p=None, intra_period=-1,
+                  reset_interval=32, bin_path=None, rec_path=None, verbose=0, verbose_json=False, device="cuda:0"):
+    """Encodes `frame_num` frames of a YUV 4:2:0 file into the reference's container (optionally written to
+    bin_path), decodes the container again, and returns the reference-schema log.  i_net / p_net: DMCI / DMC
+    (weights loaded, .update() called, on `device`, optionally .half())."""
+    import torch
+    dev = torch.device(device)
+    dtype = next(p_net.parameters()).dtype
+    two = use_two_entropy_coders(height, width)
+    for m in (i_net, p_net):
+        m.set_use_two_entropy_coders(two)
+    t_start = time.time()
+    reader = YUV420FileReader(src_path, width, height)
+    enc = SequenceEncoder(i_net, p_net, qp_i, qp_p, intra_period, reset_interval)
+    out = io.BytesIO()
+    writer = StreamWriter(out)
+    frame_types, bits, enc_time, dec_time, psnrs, ssims = [], [], [], [], [], []
+    for _ in range(frame_num):
+        y, u, v = _to_device(reader.read(), dev)
+        torch.cuda.synchronize(dev)
+        t0 = time.time()
+        pkt = enc.encode(load_yuv420_frame(y, u, v, dtype))
+        bits.append(8 * writer.write_frame(height, width, two, pkt))
+        torch.cuda.synchronize(dev)
+        enc_time.append(time.time() - t0)
+        frame_types.append(0 if pkt.is_i else 1)
+    reader.close()
+    stream = out.getvalue()
+    if bin_path:
+        with open(bin_path, "wb") as f:
+            f.write(stream)
+
+    reader = YUV420FileReader(src_path, width, height)
+    stream_reader = StreamReader(io.BytesIO(stream))
+    rec = open(rec_path, "wb") if rec_path else None
+    from .pipeline import FramePacket
+    dec = SequenceDecoder(i_net, p_net, height, width, two)
+    for _ in range(frame_num):
+        y, u, v = _to_device(reader.read(), dev)
+        torch.cuda.synchronize(dev)
+        t0 = time.time()
+        sps, is_i, qp, payload = stream_reader.read_frame()
+        dec.h, dec.w, dec.two = sps["height"], sps["width"], bool(sps["ec_part"])
+        x_hat = dec.decode(FramePacket(is_i, qp, sps["use_ada_i"], payload))
+        torch.cuda.synchronize(dev)
+        dec_time.append(time.time() - t0)
+        psnrs.append(yuv420_distortion(x_hat, y, u, v))
+        ssims.append([0.0, 0.0, 0.0, 0.0])
+        if rec is not None:     # clamp * 255, Y rounded, chroma truncated (test_video.py:307-311)
+            for plane in store_yuv420_frame(x_hat, height, width):
+                rec.write(plane.cpu().numpy().tobytes())
+    reader.close()
+    if rec is not None:
+        rec.close()
+    test_time = time.time() - t_start
+    avg_e = avg_d = None
+    if verbose >= 1 and frame_num > 10:     # the first 10 frames are warm-up (test_video.py:328-333)
+        avg_e = sum(enc_time[10:]) / len(enc_time[10:])
+        avg_d = sum(dec_time[10:]) / len(dec_time[10:])
+    return summarize(height * width, test_time, frame_types, bits, psnrs, ssims, verbose=verbose_json,
+                     avg_encoding_time=avg_e, avg_decoding_time=avg_d)
+
+
+def run_sweep(make_nets, src_path, width, height, frame_num, rate_num=4, qp_i=None, qp_p=None, **kw):
+    """RD points of one sequence: {qp_i: log}.  make_nets() -> (i_net, p_net) ready to use."""
+    qi = list(qp_i) if qp_i is not None else sweep_qps(rate_num)
+    qp = list(qp_p) if qp_p is not None else qi
+    i_net, p_net = make_nets()
+    return {q: run_one_point(i_net, p_net, src_path, width, height, frame_num, q, qq, **kw) for q, qq in zip(qi, qp)}
+
+
+def main(argv=None):
+    import argparse
+    import torch
+    from . import weights
+    from .models import DMC, DMCI
+    ap = argparse.ArgumentParser(description="DCVC-RT rate points of one YUV 4:2:0 sequence on the MI355X path")
+    ap.add_argument("--src", required=True)
+    ap.add_argument("--width", type=int, required=True)
+    ap.add_argument("--height", type=int, required=True)
+    ap.add_argument("--frames", type=int, required=True)
+    ap.add_argument("--rate-num", type=int, default=4)
+    ap.add_argument("--qp-i", type=int, nargs="*")
+    ap.add_argument("--qp-p", type=int, nargs="*")
+    ap.add_argument("--intra-period", type=int, default=-1)
+    ap.add_argument("--reset-interval", type=int, default=32)
+    ap.add_argument("--model-i", help="DMCI checkpoint (.pth.tar); synthetic weights if omitted")
+    ap.add_argument("--model-p", help="DMC checkpoint")
+    ap.add_argument("--force-zero-thres", type=float, default=0.12)
+    ap.add_argument("--fp32", action="store_true")
+    ap.add_argument("--bin-prefix", help="write <prefix>_q<qp>.bin")
+    ap.add_argument("--out", help="JSON output path (default: stdout)")
+    ap.add_argument("--verbose", type=int, default=1)
+    args = ap.parse_args(argv)
+
+    def make_nets():
+        nets = []
+        for cls, name, path in ((DMCI, "dmci", args.model_i), (DMC, "dmc", args.model_p)):
+            m = cls()
+            if path:
+                ck = torch.load(path, map_location="cpu", weights_only=True)
+                ck = ck.get("state_dict", ck)
+                ck = ck.get("net", ck)
+                m.load_state_dict({k[7:] if k.startswith("module.") else k: v for k, v in ck.items()})
+            else:
+                m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in
+                                   weights.make_state_dict(name, 1234).items()})
+            m.to("cuda").eval()
+            m.update(args.force_zero_thres)
+            if not args.fp32:
+                m.half()
+            nets.append(m)
+        return nets
+
+    res = {}
+    qi = args.qp_i if args.qp_i else sweep_qps(args.rate_num)
+    qp = args.qp_p if args.qp_p else qi
+    i_net, p_net = make_nets()
+    for a, b in zip(qi, qp):
+        res[str(a)] = run_one_point(i_net, p_net, args.src, args.width, args.height, args.frames, a, b,
+                                    args.intra_period, args.reset_interval,
+                                    bin_path=f"{args.bin_prefix}_q{a}.bin" if args.bin_prefix else None,
+                                    verbose=args.verbose)
+    text = json.dumps(res, indent=2)
+    if args.out:
+        with open(args.out, "w") as f:
+            f.write(text)
+    else:
+        print(text)
+
+
+if __name__ == "__main__":
+    main()
