@@ -255,6 +255,16 @@ def main():
             "enc_fps_per_gpu": round(n_seq / state["t_enc"], 2), "dec_fps_per_gpu": round(n_seq / state["t_dec"], 2),
             "bpp": round(state["bytes"] * 8.0 / (K * HEIGHT * WIDTH), 5),
         }
+        # whole-frame fractions (conv-hook GFLOP and fused-unit algorithmic bytes of a steady P frame at
+        # 1088x1920, scaled by the padded pixel count) from the per-direction times of the sequential pass
+        scale = ((WIDTH + (-WIDTH) % 16) * (HEIGHT + (-HEIGHT) % 16)) / (1920.0 * 1088.0)
+        t_enc, t_dec = state["t_enc"] / n_seq, state["t_dec"] / n_seq
+        out["frame_roofline"] = {
+            "enc_tflops": round(590.4e9 * scale / t_enc / 1e12, 1), "dec_tflops": round(691.6e9 * scale / t_dec / 1e12, 1),
+            "enc_frac_mfma": round(590.4e9 * scale / t_enc / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+            "dec_frac_mfma": round(691.6e9 * scale / t_dec / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+            "enc_frac_hbm": round(0.76e9 * scale / t_enc / 8.0e12, 4), "dec_frac_hbm": round(0.78e9 * scale / t_dec / 8.0e12, 4),
+            "note": "P-frame work only; the timed pass includes the GOP's I frame and the host entropy coding"}
         out["roofline"] = roofline_leg(pe, device, dtype)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg()
