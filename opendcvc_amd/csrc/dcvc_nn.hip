@@ -27,9 +27,14 @@ struct Tile {
     static constexpr int TH = M / TW;
 };
 
-template <typename T>
+#ifndef DCVC_PF_SMALL
+#define DCVC_PF_SMALL 4
+#endif
+template <typename T, int MT = 4>
 struct Pf {   // weight prefetch depth (reduction groups in flight per wave)
-    static constexpr int value = 2;   // divides every k-group count (C is a multiple of 64); deeper rings only cost registers
+    // 32-pixel tiles use a weight fragment for two MFMAs only: they are bound by latency x bytes in flight of the
+    // weight stream (Little's law), not by the MFMA pipe - a deeper ring buys bandwidth there
+    static constexpr int value = (sizeof(T) == 2 && MT == 2) ? DCVC_PF_SMALL : 2;
 };
 
 struct SrcPair {   // channel-concat of up to two HWC sources
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(NTHREADS) void dcb_head_kernel(HeadParams p)
 {
     using TR = Traits<T>;
     using frag_t = typename TR::frag_t;
-    constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH, V = TR::kVec, PF = Pf<T>::value;
+    constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH, V = TR::kVec, PF = Pf<T, MT>::value;
     extern __shared__ __attribute__((aligned(32))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Kin = p.src.c0 + p.src.c1;
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
     constexpr int NTHREADS_ = NW * 64;    // v tiles per wave per chunk
     using LD = TailLds<T, MT, NTV, NW>;
     constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH, V = TR::kVec;
-    constexpr int PF = Pf<T>::value;
+    constexpr int PF = Pf<T, MT>::value;
     constexpr int PF3 = PF;   // GEMM3 has few MFMAs per k-group: look further ahead
     constexpr int VC = NW * NTV * 16;          // v columns per chunk
     static_assert(VC == LD::VC, "chunk width");
@@ -588,7 +593,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvParams p)
 {
     using TR = Traits<T>;
     using frag_t = typename TR::frag_t;
-    constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH, PF = Pf<T>::value;
+    constexpr int M = Tile<MT>::M, TW = Tile<MT>::TW, TH = Tile<MT>::TH, PF = Pf<T>::value;   // (depth 4 measured slower here)
     extern __shared__ __attribute__((aligned(32))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Kin = p.src.c0 + p.src.c1;
