@@ -70,7 +70,7 @@ class EncodeDecodePipeline:
     coding overlaps the other stage's kernels.  (The reference runs the two loops one after the other,
     test_video.py:164-214 then :258-285; the frames, packets and reconstructions are the same.)"""
 
-    def __init__(self, encoder, decoder, device, depth=2):
+    def __init__(self, encoder, decoder, device, depth=4):
         import torch
         self.encoder, self.decoder, self.device, self.depth = encoder, decoder, device, depth
         # (a high-priority decoder stream was measured: no difference - the pair is GPU-bound either way)
