@@ -78,7 +78,7 @@ def make_frames(seed, dtype, device):
 def roofline_leg(p_net, device, dtype):
     """HIP-event timing of the dominant kernel on its own stream."""
     blk = p_net._layers["fe2"][0]          # DepthConvBlock C=256 at H/8 x W/8
-    H, W, C = (HEIGHT + 7) // 8, WIDTH // 8, 256
+    H, W, C = (HEIGHT + (-HEIGHT) % 16) // 8, (WIDTH + (-WIDTH) % 16) // 8, 256     # feature map of the padded frame
     x = (torch.randn((H, W, C), device=device) * 0.5).to(dtype)
     out = torch.empty_like(x)
     lib = _lib.lib()
