@@ -85,7 +85,7 @@ def roofline_leg(p_net, device, dtype):
     scratch = L.Scratch.get(lib.dcvc_dcb_scratch_bytes(blk.h, H, W), device)
     head, tail = ctypes.c_float(), ctypes.c_float()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for iters in (5, 30):
+    for iters in (20, 300):     # sustained enough for the clocks to settle (30 launches read ~8 % slower)
         _lib.check(lib.dcvc_dcb_profile(blk.h, L._p(x), C, C, H, W, L._p(out), C, L._p(scratch), st, iters,
                                         ctypes.byref(head), ctypes.byref(tail)), "dcvc_dcb_profile")
     P = H * W
