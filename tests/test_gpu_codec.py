@@ -146,3 +146,44 @@ def test_graph_replay_equals_plain_launches():
     for fi, ((b0, x0), (b1, x1)) in enumerate(zip(*results)):
         assert b0 == b1, f"frame {fi}: packet differs between graph replay and plain launches"
         assert np.array_equal(x0, x1), f"frame {fi}: reconstruction differs"
+
+
+@pytest.mark.parametrize("qp,thres,two,hw", [(0, 0.12, 0, (64, 64)), (63, 0.12, 0, (64, 64)), (32, None, 1, (64, 64)),
+                                             (32, 100.0, 1, (64, 64)), (17, 0.12, 0, (48, 112))])
+def test_fp32_edge_cases_bit_exact_with_oracle(qp, thres, two, hw):
+    """qp at both ends of the table (P frames reach the extra entries 64..71), no force-zero threshold, a threshold
+    that skips every y symbol (the y part of the stream is empty), a non-square map: HIP fp32 == oracle, streams
+    and reconstructions, I + 2 P frames, separate encoder-side and decoder-side models."""
+    h, w = hw
+    hip = [hip_codecs(1234, thres, torch.float32) for _ in range(2)]          # [(i, p) encoder side, (i, p) decoder side]
+    ora = []
+    for _ in range(2):
+        i_o, p_o = O.OracleDMCI(weights.make_state_dict("dmci", 1234)), O.OracleDMC(weights.make_state_dict("dmc", 1234))
+        i_o.update(thres)
+        p_o.update(thres)
+        ora.append((i_o, p_o))
+    for pair in hip + ora:
+        for m in pair:
+            m.set_use_two_entropy_coders(bool(two))
+    sps = dict(height=h, width=w, ec_part=two, use_ada_i=0)
+    for fi in range(3):
+        x = weights.synthetic_frame_yuv444(h, w, fi, 0)
+        xd = torch.from_numpy(x).cuda()
+        if fi == 0:
+            eh, eo = hip[0][0].compress(xd, qp), ora[0][0].compress(x, qp)
+            cur = qp
+        else:
+            cur = hip[0][1].shift_qp(qp, [0, 1, 0, 2][fi % 4])
+            eh, eo = hip[0][1].compress(xd, cur), ora[0][1].compress(x, cur)
+        assert eh["bit_stream"] == eo["bit_stream"], f"frame {fi}: stream differs from the oracle"
+        if thres is not None and thres > 50 and fi > 0:
+            assert len(eh["bit_stream"]) < 400                                # only z survives
+        net = 0 if fi == 0 else 1
+        dh = hip[1][net].decompress(eh["bit_stream"], sps, cur)
+        do = ora[1][net].decompress(eo["bit_stream"], sps, cur)
+        assert np.array_equal(dh["x_hat"].cpu().numpy(), np.asarray(do["x_hat"])), f"frame {fi}: reconstruction differs"
+        if fi == 0:
+            hip[0][1].clear_dpb(); hip[0][1].add_ref_frame(None, eh["x_hat"])
+            hip[1][1].clear_dpb(); hip[1][1].add_ref_frame(None, dh["x_hat"])
+            ora[0][1].clear_dpb(); ora[0][1].add_ref_frame(None, eo["x_hat"])
+            ora[1][1].clear_dpb(); ora[1][1].add_ref_frame(None, do["x_hat"])
