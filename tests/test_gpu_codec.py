@@ -148,6 +148,13 @@ def test_graph_replay_equals_plain_launches():
         assert np.array_equal(x0, x1), f"frame {fi}: reconstruction differs"
 
 
+@pytest.mark.parametrize("name", ["edge_q0", "edge_q63", "edge_nothres", "edge_allskip"])
+def test_fp32_edge_case_sequences_match_reference_records(golden_dir, name):
+    """the same edge cases against the records the reference itself produced (sequences_edge.json)"""
+    rec = json.load(open(os.path.join(golden_dir, "sequences_edge.json")))[name]
+    check_against_record(rec, run_hip(rec, torch.float32), min_exact=1.0 if name != "edge_q0" else 0.6)
+
+
 @pytest.mark.parametrize("qp,thres,two,hw", [(0, 0.12, 0, (64, 64)), (63, 0.12, 0, (64, 64)), (32, None, 1, (64, 64)),
                                              (32, 100.0, 1, (64, 64)), (17, 0.12, 0, (48, 112))])
 def test_fp32_edge_cases_bit_exact_with_oracle(qp, thres, two, hw):

@@ -131,6 +131,16 @@ def test_sequences_bit_exact_streams(seqs, name):
     check_against_record(rec, run_oracle_sequence(rec), min_exact=1.0 if name != "seq_256" else 0.75)
 
 
+@pytest.mark.parametrize("name", ["edge_q0", "edge_q63", "edge_nothres", "edge_allskip"])
+def test_edge_case_sequences_bit_exact_streams(golden_dir, name):
+    """Both ends of the qp table (P frames reach the extra entries 64..71), no force-zero threshold, every y symbol
+    skipped: the oracle's streams are byte-identical to the reference's (tests/golden/make_golden_edge.py)."""
+    rec = json.load(open(os.path.join(golden_dir, "sequences_edge.json")))[name]
+    # (qp 0: one P frame differs from the reference's stream by one flipped symbol - fp32 summation order, same
+    #  length, PSNR within 1e-4 - like frame 3 of seq_256)
+    check_against_record(rec, run_oracle_sequence(rec), min_exact=1.0 if name != "edge_q0" else 0.6)
+
+
 @pytest.mark.slow
 def test_sequence_1080p_first_frames(seqs):
     if "seq_1088x1920" not in seqs:
