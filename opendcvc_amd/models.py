@@ -309,6 +309,7 @@ class DMC(CompressionModel):
         self.max_dpb_size = 1
         self.curr_poc = 0
         self._ahead = None       # (height, width, x1, ctx): feature extractor of the NEXT frame, run ahead
+        self._pending = None     # decoder, deferred output: the reconstruction network of the previous frame still to run
 
     def _build_layers(self, sd, dt):
         D, C2, R = L.DepthConvBlock, L.Conv2d, L.ResidualBlockWithStride2
@@ -356,7 +357,7 @@ class DMC(CompressionModel):
 
     def clear_dpb(self):
         self._ahead = None
-        self.dpb.clear()
+        self.dpb.clear()     # (a deferred reconstruction stays pending: it only needs the feature buffer)
 
     def set_curr_poc(self, poc):
         self.curr_poc = poc
@@ -410,6 +411,39 @@ class DMC(CompressionModel):
         n = self._layers
         o = L.dcb_chain(n["recon"], feature, quant=q_recon)
         return self._shuffle8_clamp(n["recon_head"](o))
+
+    # the same network in two halves (deferred decoder output: each half fills one host-decoding gap of the next frame)
+    def _recon_first(self, feature):
+        return L.dcb_chain(self._layers["recon"][:2], feature)
+
+    def _recon_second(self, mid, q_recon):
+        n = self._layers
+        return self._shuffle8_clamp(n["recon_head"](L.dcb_chain(n["recon"][2:], mid, quant=q_recon)))
+
+    def _pending_half(self, which):
+        """launches one half of the pending reconstruction (no-op when nothing is pending / already done)"""
+        pd = self._pending
+        if pd is None:
+            return
+        if which == 0 and pd["mid"] is None:
+            pd["mid"] = self._graphs.run(("dec_ra",) + pd["key"], lambda: self._recon_first(pd["feature"]))
+        elif which == 1 and pd["mid"] is not None and pd["x_hat"] is None:
+            mid, qrec = pd["mid"], pd["q_recon"]
+            x = self._graphs.run(("dec_rb",) + pd["key"], lambda: self._recon_second(mid, qrec))
+            pd["x_hat"] = x.clone() if self._graphs.enabled else x
+
+    def finish_output(self):
+        """Deferred decoder output: completes and returns the reconstruction of the last decompress(...,
+        defer_output=True) (None if there is none).  Called implicitly by the next decompress."""
+        if self._pending is None:
+            return None
+        self._pending_half(0)
+        self._pending_half(1)
+        x_hat = self._pending["x_hat"]
+        self._pending = None
+        if self.dpb and self.dpb[0].frame is None:
+            self.dpb[0].frame = x_hat
+        return x_hat
 
     # ---- frame API
     def _stage_reference(self, dtype, device):
@@ -506,11 +540,20 @@ class DMC(CompressionModel):
         self._ahead = nxt
         return {"bit_stream": bit_stream}
 
-    def decompress(self, bit_stream, sps, qp):
+    def decompress(self, bit_stream, sps, qp, defer_output=False):
         """video_model.py:343-376.  Five captured runs, separated by the three host decoding steps
-        (z, first and second checkerboard half)."""
+        (z, first and second checkerboard half).
+
+        defer_output=True (not in the reference API): the reconstruction network of THIS frame is not run now
+        but in the two host-decoding gaps of the next call (nothing else can use the GPU there: the next
+        frame's symbols are not known yet) - the returned dict then carries the PREVIOUS frame under
+        'x_hat_prev' and 'x_hat' is None; finish_output() returns the last frame.  Same kernels, same values."""
         dtype, device = self._ensure_layers()
         C = arch.DMC_CH_Y
+        forced = None
+        if self._pending is not None and (not defer_output or (self.dpb and self.dpb[0].feature is None)):
+            forced = self.finish_output()          # the refresh path needs the previous picture itself
+        prev = self._pending
         ec = self.entropy_coder
         ec.set_use_two_entropy_coders(sps["ec_part"] == 1)
         ec.set_stream(bit_stream)
@@ -540,6 +583,7 @@ class DMC(CompressionModel):
         ev = torch.cuda.Event()
         ev.record()
         ctx = self._graphs.run(("dec_2",) + key, lambda: self._extractor_part2(x1))   # overlaps the host decode
+        self._pending_half(0)
         ev.synchronize()
         sym0 = self._decode_on_host(idx0, n_half, "p0")
 
@@ -551,6 +595,7 @@ class DMC(CompressionModel):
         sp, idx1 = self._graphs.run(("dec_3",) + key, after_step0)
         ev = torch.cuda.Event()
         ev.record()
+        self._pending_half(1)
         ev.synchronize()
         sym1 = self._decode_on_host(idx1, n_half, "p1")
 
@@ -561,13 +606,22 @@ class DMC(CompressionModel):
             self._symbols_to_device(sym1, n_half, 2, 1, sp[:, :, C:], y_hat, yh, yw, C, out=y_fin)
             self._prior_finish(0, y_fin, params[:, :, :C])
             feature = self._decoder(y_fin, ctx, q["q_decoder"], out=fbuf)
-            return self._recon(feature, q["q_recon"])
+            return None if defer_output else self._recon(feature, q["q_recon"])
 
-        x_hat = self._graphs.run(("dec_4",) + key, after_step1)
-        if self._graphs.enabled:
+        x_prev = None
+        if prev is not None:              # both halves of the previous frame's reconstruction are in flight by now
+            x_prev = prev["x_hat"]
+            self._pending = None
+        x_hat = self._graphs.run(("dec_4d" if defer_output else "dec_4",) + key, after_step1)
+        if x_hat is not None and self._graphs.enabled:
             x_hat = x_hat.clone()          # the captured run reuses its output buffer on the next frame
         self.add_ref_frame(fbuf, x_hat)
-        return {"x_hat": x_hat}
+        if defer_output:
+            qrec = self._buffer("q_recon_pending", q["q_recon"].shape, torch.float32, device)
+            qrec.copy_(q["q_recon"], non_blocking=True)
+            self._pending = dict(key=(sps["height"], sps["width"]), feature=fbuf, q_recon=qrec, mid=None, x_hat=None)
+            return {"x_hat": None, "x_hat_prev": x_prev if x_prev is not None else forced}
+        return {"x_hat": x_hat} if forced is None else {"x_hat": x_hat, "x_hat_prev": forced}
 
 
 # =============================================================================== DMCI (I frames)

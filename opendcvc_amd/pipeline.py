@@ -46,22 +46,41 @@ class SequenceEncoder:
 
 
 class SequenceDecoder:
-    def __init__(self, i_net, p_net, height, width, use_two):
+    """defer_output=False: decode(pkt) returns the packet's picture (the reference's loop).
+    defer_output=True: P pictures come out one call late - decode(pkt) returns a LIST of the pictures completed
+    by the call, in order (usually one: the previous frame), flush() the rest; the reconstruction network of a
+    P frame then runs inside the host entropy-decoding gaps of the next frame (DMC.decompress)."""
+
+    def __init__(self, i_net, p_net, height, width, use_two, defer_output=False):
         self.i_net, self.p_net = i_net, p_net
         self.h, self.w, self.two = height, width, use_two
+        self.defer = defer_output
         p_net.set_curr_poc(0)
 
     def decode(self, pkt):
         sps = dict(height=self.h, width=self.w, ec_part=1 if self.two else 0, use_ada_i=pkt.use_ada_i)
+        done = []
         if pkt.is_i:
+            if self.defer:
+                last = self.p_net.finish_output()
+                if last is not None:
+                    done.append(last)
             dec = self.i_net.decompress(pkt.bit_stream, sps, pkt.qp)
             self.p_net.clear_dpb()
             self.p_net.add_ref_frame(None, dec["x_hat"])
+            done.append(dec["x_hat"])
         else:
             if pkt.use_ada_i:
                 self.p_net.reset_ref_feature()
-            dec = self.p_net.decompress(pkt.bit_stream, sps, pkt.qp)
-        return dec["x_hat"]
+            dec = self.p_net.decompress(pkt.bit_stream, sps, pkt.qp, defer_output=self.defer)
+            for k in ("x_hat_prev", "x_hat"):
+                if dec.get(k) is not None:
+                    done.append(dec[k])
+        return done if self.defer else done[-1]
+
+    def flush(self):
+        last = self.p_net.finish_output() if self.defer else None
+        return [] if last is None else [last]
 
 
 class EncodeDecodePipeline:
@@ -77,11 +96,20 @@ class EncodeDecodePipeline:
         self.enc_stream, self.dec_stream = torch.cuda.Stream(device), torch.cuda.Stream(device)
         self._warm = 0
 
+    @staticmethod
+    def _emit(frames, on_frame):
+        if on_frame is not None:
+            for x in (frames if isinstance(frames, list) else [frames]):
+                on_frame(x)
+
     def _captured(self):
         eg, dg = self.encoder.p_net._graphs, self.decoder.p_net._graphs
         if not (eg.enabled and dg.enabled):
             return True
-        done = all(("i" in v and "p" in v) for v in (eg.variants("enc_back"), dg.variants("dec_4")))
+        dv = dg.variants("dec_4d") if getattr(self.decoder, "defer", False) else dg.variants("dec_4")
+        done = all(("i" in v and "p" in v) for v in (eg.variants("enc_back"), dv))
+        if done and getattr(self.decoder, "defer", False):
+            done = bool(dg.variants("dec_rb"))
         return done or self._warm >= 40      # (an all-intra sequence never captures the "p" variant)
 
     def run(self, frames, on_packet=None, on_frame=None):
@@ -99,6 +127,9 @@ class EncodeDecodePipeline:
         while not self._captured():
             x = next(frames, None)
             if x is None:
+                with torch.cuda.stream(self.dec_stream):
+                    self._emit(self.decoder.flush(), on_frame)
+                self.dec_stream.synchronize()
                 return
             with torch.cuda.stream(self.enc_stream):
                 pkt = self.encoder.encode(x)
@@ -106,9 +137,7 @@ class EncodeDecodePipeline:
                     on_packet(pkt)
             self.enc_stream.synchronize()
             with torch.cuda.stream(self.dec_stream):
-                x_hat = self.decoder.decode(pkt)
-                if on_frame is not None:
-                    on_frame(x_hat)
+                self._emit(self.decoder.decode(pkt), on_frame)
             self.dec_stream.synchronize()
             self._warm += 1
         q = queue.Queue(maxsize=self.depth)
@@ -137,9 +166,8 @@ class EncodeDecodePipeline:
                         pkt = q.get()
                         if pkt is None:
                             break
-                        x_hat = self.decoder.decode(pkt)
-                        if on_frame is not None:
-                            on_frame(x_hat)
+                        self._emit(self.decoder.decode(pkt), on_frame)
+                    self._emit(self.decoder.flush(), on_frame)
                     self.dec_stream.synchronize()
             except BaseException as e:
                 errors.append(e)

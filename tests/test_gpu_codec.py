@@ -92,6 +92,36 @@ def test_requires_update_and_cuda():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_deferred_decoder_output_equals_immediate(dtype):
+    """SequenceDecoder(defer_output=True): the reconstruction network of a P frame runs inside the next frame's
+    host-decoding gaps and the picture comes out one call late - same pictures, same order, across I frames
+    (intra period 4) and feature refreshes (reset interval 3)."""
+    from opendcvc_amd.pipeline import SequenceDecoder, SequenceEncoder
+    h, w, n = 96, 160, 9
+    frames = [torch.from_numpy(weights.synthetic_frame_yuv444(h, w, fi, 7)).to("cuda", dtype) for fi in range(n)]
+    ie, pe = hip_codecs(1234, 0.12, dtype)
+    for m in (ie, pe):
+        m.set_use_two_entropy_coders(False)
+    enc = SequenceEncoder(ie, pe, 28, intra_period=4, reset_interval=3)
+    pkts = [enc.encode(x) for x in frames]
+    outs = []
+    for defer in (False, True):
+        idc, pdc = hip_codecs(1234, 0.12, dtype)
+        for m in (idc, pdc):
+            m.set_use_two_entropy_coders(False)
+        dec = SequenceDecoder(idc, pdc, h, w, False, defer_output=defer)
+        got = []
+        for pkt in pkts:
+            r = dec.decode(pkt)
+            got += [t.float().cpu().numpy() for t in (r if defer else [r])]
+        got += [t.float().cpu().numpy() for t in dec.flush()]
+        outs.append(got)
+    assert len(outs[0]) == len(outs[1]) == n
+    for fi, (a, b) in enumerate(zip(*outs)):
+        assert np.array_equal(a, b), f"frame {fi}: deferred output differs"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_two_stage_pipeline_equals_sequential(dtype):
     """EncodeDecodePipeline (encoder / decoder on two host threads and HIP streams) = the plain
     encode-then-decode loop: same packets, same reconstructions, frame for frame."""
@@ -112,6 +142,7 @@ def test_two_stage_pipeline_equals_sequential(dtype):
         pkt = enc.encode(x)
         want.append((pkt, dec.decode(pkt).float().cpu().numpy()))
     enc, dec = codecs()
+    dec.defer = True                      # the pipeline's usual configuration: decoder output one frame late
     pkts, outs = [], []
     EncodeDecodePipeline(enc, dec, torch.device("cuda", 0)).run(
         frames, on_packet=pkts.append, on_frame=lambda t: outs.append(t.float().cpu().numpy()))
