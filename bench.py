@@ -135,7 +135,7 @@ def cpu_baseline_leg():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)      # two whole GOPs: the timed frames hold I frames at the GOP's rate (1 in 32)
+    ap.add_argument("--steps", type=int, default=256)     # eight whole GOPs (I frames at the GOP's rate, 1 in 32), under a second
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frame", default="1920x1080",
