@@ -132,11 +132,20 @@ class EntropyCoder:
             pass
 
     def pinned(self, key, nbytes):
-        b = self._pinned.get(key)
-        if b is None or b.nbytes < nbytes:
-            b = PinnedBuffer(nbytes)
-            self._pinned[key] = b
+        """Pinned staging buffer for (key, nbytes).  One buffer per distinct size, never replaced or freed while
+        the coder lives: captured HIP graphs (models.GraphCache) keep the raw host pointer in their memcpy
+        nodes, so a buffer handed out once must stay valid and keep its meaning for that (key, size)."""
+        k = (key, int(nbytes))
+        b = self._pinned.get(k)
+        if b is None:
+            b = self._pinned[k] = PinnedBuffer(nbytes)
         return b
+
+    def adopt_pinned(self, other):
+        """takes over another coder's staging buffers (CompressionModel.update() called again: graphs captured
+        earlier may still reference them)"""
+        if other is not None:
+            self._pinned.update(other._pinned)
 
     def add_cdf(self, cdf, cdf_length, offset):
         L = _lib.lib()

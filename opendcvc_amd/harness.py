@@ -200,12 +200,19 @@ def run_one_point(i_net, p_net, src_path, width, height, frame_num, qp_i, qp_p=N
                      avg_encoding_time=avg_e, avg_decoding_time=avg_d)
 
 
-def run_sweep(make_nets, src_path, width, height, frame_num, rate_num=4, qp_i=None, qp_p=None, **kw):
-    """RD points of one sequence: {qp_i: log}.  make_nets() -> (i_net, p_net) ready to use."""
+def run_sweep(make_nets, src_path, width, height, frame_num, rate_num=4, qp_i=None, qp_p=None, bin_prefix=None, **kw):
+    """RD points of one sequence (test_video.py:448-463 + the per-point loop :472-510): {qp_i: log}.
+    make_nets() -> (i_net, p_net) ready to use; one pair codes every point, like a reference worker.
+    bin_prefix: write each point's container to <prefix>_q<qp_i>.bin (the reference's naming, test_video.py:367)."""
     qi = list(qp_i) if qp_i is not None else sweep_qps(rate_num)
     qp = list(qp_p) if qp_p is not None else qi
     i_net, p_net = make_nets()
-    return {q: run_one_point(i_net, p_net, src_path, width, height, frame_num, q, qq, **kw) for q, qq in zip(qi, qp)}
+    out = {}
+    for q, qq in zip(qi, qp):
+        out[q] = run_one_point(i_net, p_net, src_path, width, height, frame_num, q, qq,
+                               bin_path=f"{bin_prefix}_q{q}.bin" if bin_prefix else None, **kw)
+        out[q].update(qp_i=q, qp_p=qq)          # the keys test_video.worker adds to a point's result (:373-376)
+    return out
 
 
 def main(argv=None):
@@ -230,6 +237,7 @@ def main(argv=None):
     ap.add_argument("--bin-prefix", help="write <prefix>_q<qp>.bin")
     ap.add_argument("--out", help="JSON output path (default: stdout)")
     ap.add_argument("--verbose", type=int, default=1)
+    ap.add_argument("--verbose-json", action="store_true", help="per-frame lists in the log (reference --verbose_json)")
     args = ap.parse_args(argv)
 
     def make_nets():
@@ -251,16 +259,11 @@ def main(argv=None):
             nets.append(m)
         return nets
 
-    res = {}
-    qi = args.qp_i if args.qp_i else sweep_qps(args.rate_num)
-    qp = args.qp_p if args.qp_p else qi
-    i_net, p_net = make_nets()
-    for a, b in zip(qi, qp):
-        res[str(a)] = run_one_point(i_net, p_net, args.src, args.width, args.height, args.frames, a, b,
-                                    args.intra_period, args.reset_interval,
-                                    bin_path=f"{args.bin_prefix}_q{a}.bin" if args.bin_prefix else None,
-                                    verbose=args.verbose)
-    text = json.dumps(res, indent=2)
+    res = run_sweep(make_nets, args.src, args.width, args.height, args.frames, args.rate_num,
+                    args.qp_i or None, args.qp_p or None, bin_prefix=args.bin_prefix,
+                    intra_period=args.intra_period, reset_interval=args.reset_interval, verbose=args.verbose,
+                    verbose_json=args.verbose_json)
+    text = json.dumps({str(k): v for k, v in res.items()}, indent=2)
     if args.out:
         with open(args.out, "w") as f:
             f.write(text)

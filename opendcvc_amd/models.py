@@ -34,6 +34,91 @@ def _register(root, dotted, tensor):
     m.register_parameter(parts[-1], tnn.Parameter(tensor, requires_grad=False))
 
 
+class _CaptureGuard:
+    """Process-wide reader/writer gate around HIP graph capture.
+
+    A capture in flight is invalidated by a device synchronisation, an allocation or a free issued by ANOTHER
+    host thread (the two-stage pipeline runs the encoder and the decoder on two threads).  Every per-frame
+    call of a codec runs inside `frame()` (shared); a capture takes the gate exclusively: it waits until the
+    other threads have left their current frame and keeps them from starting the next one until the capture
+    has ended.  Work those threads already queued on their streams keeps running on the GPU - only their host
+    API calls are held back.  Uncontended cost: one lock round trip per frame."""
+
+    def __init__(self):
+        import threading
+        self._cv = threading.Condition()
+        self._active = 0          # threads inside a frame
+        self._capturing = False
+        self._local = threading.local()
+
+    def frame(self):
+        return _FrameScope(self)
+
+    def _enter(self):
+        depth = getattr(self._local, "depth", 0)
+        self._local.depth = depth + 1
+        if depth:
+            return
+        with self._cv:
+            while self._capturing:
+                self._cv.wait()
+            self._active += 1
+
+    def _exit(self):
+        self._local.depth -= 1
+        if self._local.depth:
+            return
+        with self._cv:
+            self._active -= 1
+            self._cv.notify_all()
+
+    def capture(self):
+        return _CaptureScope(self)
+
+    def _begin_capture(self):
+        inside = getattr(self._local, "depth", 0) > 0
+        with self._cv:
+            if inside:
+                self._active -= 1             # do not wait for ourselves; lets another capturer go first
+                self._cv.notify_all()
+            while self._capturing or self._active > 0:
+                self._cv.wait()
+            self._capturing = True
+        return inside
+
+    def _end_capture(self, inside):
+        with self._cv:
+            self._capturing = False
+            if inside:
+                self._active += 1
+            self._cv.notify_all()
+
+
+class _FrameScope:
+    def __init__(self, g):
+        self.g = g
+
+    def __enter__(self):
+        self.g._enter()
+
+    def __exit__(self, *exc):
+        self.g._exit()
+
+
+class _CaptureScope:
+    def __init__(self, g):
+        self.g = g
+
+    def __enter__(self):
+        self.inside = self.g._begin_capture()
+
+    def __exit__(self, *exc):
+        self.g._end_capture(self.inside)
+
+
+CAPTURE_GUARD = _CaptureGuard()
+
+
 class GraphCache:
     """Fixed runs of kernel launches, captured once per key as a HIP graph and replayed afterwards.
 
@@ -62,8 +147,9 @@ class GraphCache:
             if self._side is None:      # capture needs a non-default stream; replay runs on the caller's
                 self._side = torch.cuda.Stream()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self._side, capture_error_mode="thread_local"):
-                out = fn()
+            with CAPTURE_GUARD.capture():       # no other host thread touches the device while this captures
+                with torch.cuda.graph(g, stream=self._side, capture_error_mode="thread_local"):
+                    out = fn()
             e = self._entries[key] = (g, out)
         e[0].replay()
         return e[1]
@@ -123,7 +209,10 @@ class CompressionModel(tnn.Module):
         """Builds the entropy coder and its CDF tables (common_model.py:49-52)."""
         _lib.lib()
         self.force_zero_thres = force_zero_thres
+        old = self.entropy_coder
         self.entropy_coder = entropy.EntropyCoder()
+        self.entropy_coder.adopt_pinned(old)      # pinned staging outlives the coder that allocated it
+        self._graphs.clear()                      # the threshold is baked into the captured runs
         self._g_group = self.entropy_coder.add_cdf(*entropy.gaussian_cdf_tables())
         sd = self.state_dict()
         pre = "bit_estimator_z."
@@ -517,7 +606,9 @@ class DMC(CompressionModel):
         ready = torch.cuda.Event()
         ready.record()
         # the decoder keeps the GPU busy while the host codes
-        self._graphs.run(("enc_back",) + key, lambda: self._decoder(y_hat, ctx, q["q_decoder"], out=fbuf))
+        # (keyed by the front run too: its y_hat / ctx are that run's static outputs)
+        self._graphs.run(("enc_back", "ahead" if ahead is not None else "full") + key,
+                         lambda: self._decoder(y_hat, ctx, q["q_decoder"], out=fbuf))
         nxt = None
         if self._graphs.enabled:     # next frame's extractor, behind the decoder and under the host coder below
             def extractor_ahead():

@@ -28,6 +28,11 @@ class SequenceEncoder:
         p_net.set_curr_poc(0)
 
     def encode(self, x_padded):
+        from .models import CAPTURE_GUARD
+        with CAPTURE_GUARD.frame():          # (a HIP graph capture on another thread waits for / holds back this frame)
+            return self._encode(x_padded)
+
+    def _encode(self, x_padded):
         fi = self.frame_idx
         self.frame_idx += 1
         if fi == 0 or (self.intra_period > 0 and fi % self.intra_period == 0):
@@ -58,6 +63,11 @@ class SequenceDecoder:
         p_net.set_curr_poc(0)
 
     def decode(self, pkt):
+        from .models import CAPTURE_GUARD
+        with CAPTURE_GUARD.frame():
+            return self._decode(pkt)
+
+    def _decode(self, pkt):
         sps = dict(height=self.h, width=self.w, ec_part=1 if self.two else 0, use_ada_i=pkt.use_ada_i)
         done = []
         if pkt.is_i:
@@ -79,7 +89,9 @@ class SequenceDecoder:
         return done if self.defer else done[-1]
 
     def flush(self):
-        last = self.p_net.finish_output() if self.defer else None
+        from .models import CAPTURE_GUARD
+        with CAPTURE_GUARD.frame():
+            last = self.p_net.finish_output() if self.defer else None
         return [] if last is None else [last]
 
 
@@ -94,23 +106,12 @@ class EncodeDecodePipeline:
         self.encoder, self.decoder, self.device, self.depth = encoder, decoder, device, depth
         # (a high-priority decoder stream was measured: no difference - the pair is GPU-bound either way)
         self.enc_stream, self.dec_stream = torch.cuda.Stream(device), torch.cuda.Stream(device)
-        self._warm = 0
 
     @staticmethod
     def _emit(frames, on_frame):
         if on_frame is not None:
             for x in (frames if isinstance(frames, list) else [frames]):
                 on_frame(x)
-
-    def _captured(self):
-        eg, dg = self.encoder.p_net._graphs, self.decoder.p_net._graphs
-        if not (eg.enabled and dg.enabled):
-            return True
-        dv = dg.variants("dec_4d") if getattr(self.decoder, "defer", False) else dg.variants("dec_4")
-        done = all(("i" in v and "p" in v) for v in (eg.variants("enc_back"), dv))
-        if done and getattr(self.decoder, "defer", False):
-            done = bool(dg.variants("dec_rb"))
-        return done or self._warm >= 40      # (an all-intra sequence never captures the "p" variant)
 
     def run(self, frames, on_packet=None, on_frame=None):
         """frames: iterable of padded model inputs (device tensors, ready on the calling stream).
@@ -119,27 +120,11 @@ class EncodeDecodePipeline:
         import queue
         import threading
         import torch
+        from .models import CAPTURE_GUARD
         torch.cuda.current_stream().synchronize()
         frames = iter(frames)
-        # HIP graph capture (GraphCache) must not overlap the other stage's work: a device synchronisation or
-        # a free on another thread invalidates a capture in flight.  Until both P-frame variants of both
-        # stages are captured (normally: the first three frames) the stages run one after the other here.
-        while not self._captured():
-            x = next(frames, None)
-            if x is None:
-                with torch.cuda.stream(self.dec_stream):
-                    self._emit(self.decoder.flush(), on_frame)
-                self.dec_stream.synchronize()
-                return
-            with torch.cuda.stream(self.enc_stream):
-                pkt = self.encoder.encode(x)
-                if on_packet is not None:
-                    on_packet(pkt)
-            self.enc_stream.synchronize()
-            with torch.cuda.stream(self.dec_stream):
-                self._emit(self.decoder.decode(pkt), on_frame)
-            self.dec_stream.synchronize()
-            self._warm += 1
+        # HIP graph captures (first frames, new resolutions, new variants) are serialised against the other
+        # stage's host calls by models.CAPTURE_GUARD inside encode() / decode(): no warm-up phase is needed.
         q = queue.Queue(maxsize=self.depth)
         errors = []
 
@@ -148,11 +133,13 @@ class EncodeDecodePipeline:
                 torch.cuda.set_device(self.device)
                 with torch.cuda.stream(self.enc_stream):
                     for x in frames:
-                        pkt = self.encoder.encode(x)
-                        if on_packet is not None:
-                            on_packet(pkt)
-                        q.put(pkt)
-                    self.enc_stream.synchronize()
+                        with CAPTURE_GUARD.frame():         # the callback may touch the device too
+                            pkt = self.encoder.encode(x)
+                            if on_packet is not None:
+                                on_packet(pkt)
+                        q.put(pkt)                          # (never block on the queue inside the scope)
+                    with CAPTURE_GUARD.frame():
+                        self.enc_stream.synchronize()
             except BaseException as e:                      # re-raised by run()
                 errors.append(e)
             finally:
@@ -166,9 +153,11 @@ class EncodeDecodePipeline:
                         pkt = q.get()
                         if pkt is None:
                             break
-                        self._emit(self.decoder.decode(pkt), on_frame)
-                    self._emit(self.decoder.flush(), on_frame)
-                    self.dec_stream.synchronize()
+                        with CAPTURE_GUARD.frame():
+                            self._emit(self.decoder.decode(pkt), on_frame)
+                    with CAPTURE_GUARD.frame():
+                        self._emit(self.decoder.flush(), on_frame)
+                        self.dec_stream.synchronize()
             except BaseException as e:
                 errors.append(e)
                 while q.get() is not None:                  # keep the encoder from blocking on a full queue

@@ -164,6 +164,66 @@ class Net:
                       ctypes.c_int64(C))
         return out
 
+    # ---- fp16-storage emulation of the HIP fp16 mode (tests only) -------------------------------------
+    # The HIP fp16 kernels keep every activation in _Float16 and accumulate in fp32.
+    # These two methods round to fp16 exactly where those kernels store (opendcvc_amd/csrc/dcvc_nn.hip:
+    # dcb_head_kernel -> x', a;  dcb_tail_kernel -> d, W2 d + b2, o, v, r, out;  conv_kernel -> out) and
+    # use the weights as dcvc_dcb_create / dcvc_conv_create pack them (pre-scaled by kAct, rounded to fp16),
+    # so that the fp16 mode has a tight reference: what remains is the fp32 summation order inside the
+    # MFMA and the hardware exp2 / rcp (about 1 ulp in fp32), i.e. rare one-ulp fp16 rounding flips.
+    K_ACT = np.float32(-5.770780163555854)          # Traits<half_t>::kAct = -4 log2(e)
+
+    @staticmethod
+    def _rh(a):
+        return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+    @classmethod
+    def _gate16(cls, up):
+        """Traits<half_t>::gate: g(u') = u' / (1 + 2^u') on the pre-scaled pre-activation (fp32)"""
+        up = np.asarray(up, np.float32)
+        with np.errstate(over="ignore"):
+            return up * (np.float32(1.0) / (np.float32(1.0) + np.exp2(up)))
+
+    def conv_f16(self, x, prefix, stride=1, pad=0, epilogue="bias", q=None):
+        """conv_kernel in fp16 mode: fp16 weights / input, fp32 accumulate + bias, epilogue in fp32,
+        one rounding to fp16 at the store.  epilogue: bias | quant (times q) | wsilu."""
+        w = self._rh(self.sd[prefix + ".weight"])
+        b = self.sd[prefix + ".bias"]
+        x = self._rh(x)
+        y = conv1x1(x, w, b) if (w.shape[2] == 1 and stride == 1) else conv2d(x, w, b, stride, pad)
+        if epilogue == "quant":
+            y = y * _f32(q).reshape(1, 1, -1)
+        elif epilogue == "wsilu":
+            with np.errstate(over="ignore"):
+                y = y * (np.float32(1.0) / (np.float32(1.0) + np.exp2(y * self.K_ACT)))
+        return self._rh(y)
+
+    def dcb_f16(self, x, prefix, shortcut=False, q=None):
+        """DepthConvBlock as dcb_head_kernel + dcb_tail_kernel compute it in fp16 mode."""
+        sd, rh, ka = self.sd, self._rh, self.K_ACT
+        g = lambda n: sd[prefix + n]
+        C = g(".dc.0.weight").shape[0]
+        x = rh(x)
+        if (prefix + ".adaptor.weight") in sd:
+            xi = rh(conv1x1(x, rh(g(".adaptor.weight")), g(".adaptor.bias")))          # x' (identity branch)
+        else:
+            xi = x
+        a = rh(self._gate16(conv1x1(xi, rh(ka * g(".dc.0.weight")), ka * g(".dc.0.bias"))))   # kAct * wsilu(.)
+        H, W, _ = a.shape
+        d = np.empty((H, W, C), np.float32)
+        wd = rh(g(".dc.2.weight") / ka)
+        lib().orc_dw3x3(_ptr(_f32(a)), H, W, C, _ptr(_f32(wd)), _ptr(_f32(g(".dc.2.bias"))), _ptr(d))
+        d = rh(d)
+        o = rh(rh(conv1x1(d, rh(g(".dc.3.weight")), g(".dc.3.bias"))) + xi)
+        u = conv1x1(o, rh(ka * g(".ffn.0.weight")), ka * g(".ffn.0.bias"))
+        v = rh(self._gate16(u[:, :, :2 * C]) + self._gate16(u[:, :, 2 * C:]))
+        r = rh(conv1x1(v, rh(g(".ffn.2.weight") / ka), g(".ffn.2.bias")) + o)
+        if shortcut:
+            r = r + xi
+        if q is not None:
+            r = r * _f32(q).reshape(1, 1, -1)
+        return rh(r)
+
     def subpel(self, x, prefix, pad):
         """SubpelConv2x (layers.py:29-52): conv -> PixelShuffle(2)."""
         return pixel_shuffle(self.conv(x, prefix + ".conv.0", 1, pad), 2)

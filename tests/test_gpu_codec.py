@@ -80,6 +80,32 @@ def test_fp16_self_consistent_and_close_to_fp32(seqs):
         assert abs(psnr_of(rec, fi, g["x_hat"]) - f["psnr"]) < 0.05
 
 
+def test_fp32_1080p_matches_reference_record(seqs):
+    """BASELINE configs[1] size (1088x1920 padded, two coders): the HIP fp32 path against the record the reference
+    itself produced (tests/golden/make_golden.py): per-frame stream length and PSNR within 1e-4 (I, P, P).
+    (1.0 M symbols per frame: a few symbols sit on a rounding boundary of the fp32 summation order, so the
+    streams are not byte-identical - the same holds for the CPU oracle, tests/test_oracle_nn.py.)"""
+    rec = seqs["seq_1088x1920"]
+    got = run_hip(rec, torch.float32)
+    check_against_record(rec, got, min_exact=0.0, tol=1e-4)
+    for fi, g in enumerate(got):
+        if fi > 0:
+            assert np.array_equal(g["dec_feature"], g["feature"]), f"frame {fi}: enc/dec feature desync"
+
+
+def test_fp16_1080p_close_to_reference_record(seqs):
+    """the benchmarked mode at the benchmarked size: rate within 2 %, PSNR within 0.05 dB of the reference's
+    fp32 record, decoder features bit-identical to the encoder's"""
+    rec = seqs["seq_1088x1920"]
+    got = run_hip(rec, torch.float16)
+    for fi, g in enumerate(got):
+        f = rec["frames"][fi]
+        if fi > 0:
+            assert np.array_equal(g["dec_feature"], g["feature"]), f"frame {fi}: fp16 enc/dec desync"
+        assert abs(len(g["bits"]) - f["bytes"]) <= 0.02 * f["bytes"], (fi, len(g["bits"]), f["bytes"])
+        assert abs(psnr_of(rec, fi, g["x_hat"]) - f["psnr"]) < 0.05, (fi, psnr_of(rec, fi, g["x_hat"]), f["psnr"])
+
+
 def test_requires_update_and_cuda():
     from opendcvc_amd._lib import DcvcError
     from opendcvc_amd.models import DMCI
@@ -173,6 +199,7 @@ def test_graph_replay_equals_plain_launches():
             out.append((pkt.bit_stream, dec.decode(pkt).float().cpu().numpy()))
         if graphs:
             assert pe._graphs.variants("enc_front_ahead") == {"p"} and pdc._graphs.variants("dec_4") == {"i", "p"}
+            assert pe._graphs.variants("enc_back") == {"full", "ahead"}
         results.append(out)
     for fi, ((b0, x0), (b1, x1)) in enumerate(zip(*results)):
         assert b0 == b1, f"frame {fi}: packet differs between graph replay and plain launches"
@@ -225,3 +252,51 @@ def test_fp32_edge_cases_bit_exact_with_oracle(qp, thres, two, hw):
             hip[1][1].clear_dpb(); hip[1][1].add_ref_frame(None, dh["x_hat"])
             ora[0][1].clear_dpb(); ora[0][1].add_ref_frame(None, eo["x_hat"])
             ora[1][1].clear_dpb(); ora[1][1].add_ref_frame(None, do["x_hat"])
+
+
+def _encode_decode(codecs_enc, codecs_dec, h, w, n, dtype, qp=30, seed=11):
+    """I + (n-1) P frames through given encoder-side / decoder-side (DMCI, DMC) pairs"""
+    from opendcvc_amd.pipeline import SequenceDecoder, SequenceEncoder
+    for m in codecs_enc + codecs_dec:
+        m.set_use_two_entropy_coders(False)
+    enc = SequenceEncoder(codecs_enc[0], codecs_enc[1], qp, intra_period=-1, reset_interval=0)
+    dec = SequenceDecoder(codecs_dec[0], codecs_dec[1], h, w, False)
+    out = []
+    for fi in range(n):
+        x = torch.from_numpy(weights.synthetic_frame_yuv444(h, w, fi, seed)).to("cuda", dtype)
+        pkt = enc.encode(x)
+        out.append((pkt.bit_stream, dec.decode(pkt).float().cpu().numpy()))
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_one_model_instance_across_resolutions(dtype):
+    """The reference harness reuses one i_frame_net / p_frame_net per worker across sequences of different sizes
+    (test_video.py init_func / worker).  Captured runs keep raw pointers to pinned staging buffers: a model that
+    codes 64x64, then 256x256, then 64x64 again must give the results of fresh instances every time."""
+    shared_e, shared_d = hip_codecs(1234, 0.12, dtype), hip_codecs(1234, 0.12, dtype)
+    for (h, w) in ((64, 64), (256, 256), (64, 64), (96, 160), (256, 256)):
+        want = _encode_decode(hip_codecs(1234, 0.12, dtype), hip_codecs(1234, 0.12, dtype), h, w, 3, dtype)
+        got = _encode_decode(shared_e, shared_d, h, w, 3, dtype)
+        for fi, ((wb, wx), (gb, gx)) in enumerate(zip(want, got)):
+            assert gb == wb, f"{h}x{w} frame {fi}: packet differs on a reused model"
+            assert np.array_equal(gx, wx), f"{h}x{w} frame {fi}: reconstruction differs on a reused model"
+
+
+def test_update_twice_keeps_working():
+    """update() rebuilds the entropy coder (new threshold): pinned staging that captured runs point at must
+    survive it, and the runs must pick up the new threshold."""
+    dtype = torch.float16
+    e, d = hip_codecs(1234, 0.12, dtype), hip_codecs(1234, 0.12, dtype)
+    first = _encode_decode(e, d, 64, 96, 3, dtype)
+    for m in e + d:
+        m.update(0.3)
+    other = _encode_decode(e, d, 64, 96, 3, dtype)
+    fe, fd = hip_codecs(1234, 0.3, dtype), hip_codecs(1234, 0.3, dtype)
+    want = _encode_decode(fe, fd, 64, 96, 3, dtype)
+    assert [b for b, _ in other] == [b for b, _ in want] and all(np.array_equal(a[1], b[1]) for a, b in zip(other, want))
+    assert [b for b, _ in other] != [b for b, _ in first]          # the threshold did change the streams
+    for m in e + d:
+        m.update(0.12)
+    again = _encode_decode(e, d, 64, 96, 3, dtype)
+    assert [b for b, _ in again] == [b for b, _ in first] and all(np.array_equal(a[1], b[1]) for a, b in zip(again, first))

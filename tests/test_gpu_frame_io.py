@@ -1,39 +1,53 @@
-"""Fused frame I/O kernels against the reference's I/O semantics restated in numpy/torch-CPU
-(src/utils/transforms.py:13-24,56-63; test_video.py:60-63,90,179,307-311)."""
+"""Fused frame I/O kernels against fixtures produced by the reference's own functions
+(tests/golden/make_golden_frameio.py: src/utils/transforms.py:13-24,56-63, test_video.py:59-63,90,179,307-311),
+plus the full-size property the fixtures are too small for."""
+import os
+
 import numpy as np
 import pytest
 import torch
-import torch.nn.functional as F
 
 from opendcvc_amd.pipeline import load_yuv420_frame, store_yuv420_frame
 
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "frame_io.npz"))
+
+
+@pytest.mark.parametrize("dtype,name", [(torch.float32, "f32"), (torch.float16, "f16")])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_yuv420_to_padded_frame_matches_reference(gold, tag, dtype, name):
+    y, u, v = (torch.from_numpy(gold[f"src_{tag}_{k}"]).cuda() for k in "yuv")
+    got = load_yuv420_frame(y, u, v, dtype)
+    want = gold[f"src_{tag}_{name}"]
+    assert got.dtype == dtype and tuple(got.shape) == want.shape
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("dtype,name", [(torch.float32, "f32"), (torch.float16, "f16")])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_frame_to_yuv420_matches_reference(gold, tag, dtype, name):
+    x = torch.from_numpy(gold[f"rec_{tag}_{name}_x"]).cuda()
+    h, w = gold[f"rec_{tag}_{name}_y"].shape
+    yy, uu, vv = store_yuv420_frame(x, h, w)
+    for got, k in ((yy, "y"), (uu, "u"), (vv, "v")):
+        assert np.array_equal(got.cpu().numpy(), gold[f"rec_{tag}_{name}_{k}"]), k
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-@pytest.mark.parametrize("h,w", [(1080, 1920), (36, 50)])
-def test_yuv420_to_padded_frame(h, w, dtype):
+def test_full_size_round_trip_property(dtype):
+    """1080p: planes -> padded frame -> planes gives the source back (Y exactly; chroma exactly, being constant over
+    each 2x2 block), and the padding rows / columns replicate the last picture row / column."""
+    h, w = 1080, 1920
     rng = np.random.default_rng(1)
-    y = rng.integers(0, 256, (h, w), dtype=np.uint8)
-    u = rng.integers(0, 256, (h // 2, w // 2), dtype=np.uint8)
-    v = rng.integers(0, 256, (h // 2, w // 2), dtype=np.uint8)
-    got = load_yuv420_frame(torch.from_numpy(y).cuda(), torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda(), dtype)
-    up = lambda a: np.repeat(np.repeat(a, 2, 0), 2, 1)                 # scipy zoom order 0 by exactly 2
-    x = np.stack([y, up(u), up(v)]).astype(np.float32)[None]
-    ref = (torch.from_numpy(x) / 255.0).to(dtype)                        # np_image_to_tensor + x.to(float16)
-    pb, pr = (-h) % 16, (-w) % 16
-    ref = F.pad(ref.float(), (0, pr, 0, pb), mode="replicate").to(dtype)
-    assert torch.equal(got.cpu(), ref)
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-def test_frame_to_yuv420(dtype):
-    rng = np.random.default_rng(2)
-    h, w, hp, wp = 36, 50, 48, 64
-    x = torch.from_numpy(rng.uniform(-0.1, 1.1, (1, 3, hp, wp)).astype(np.float32)).to(dtype)
-    yy, uu, vv = store_yuv420_frame(x.cuda(), h, w)
-    xc = x[:, :, :h, :w]
-    y_rec = torch.clamp(xc[:, :1] * 255, 0, 255).round().to(torch.uint8)[0, 0]
-    uv = F.avg_pool2d(xc[:, 1:].float(), 2, 2).to(dtype)
-    uv_rec = torch.clamp(uv * 255, 0, 255).to(torch.uint8)[0]
-    assert torch.equal(yy.cpu(), y_rec) and torch.equal(uu.cpu(), uv_rec[0]) and torch.equal(vv.cpu(), uv_rec[1])
+    y = torch.from_numpy(rng.integers(0, 256, (h, w), dtype=np.uint8)).cuda()
+    u = torch.from_numpy(rng.integers(0, 256, (h // 2, w // 2), dtype=np.uint8)).cuda()
+    v = torch.from_numpy(rng.integers(0, 256, (h // 2, w // 2), dtype=np.uint8)).cuda()
+    x = load_yuv420_frame(y, u, v, dtype)
+    assert tuple(x.shape) == (1, 3, 1088, 1920)
+    assert torch.equal(x[:, :, h:, :], x[:, :, h - 1:h, :].expand(-1, -1, 8, -1))
+    y2, u2, v2 = store_yuv420_frame(x, h, w, round_uv=True)
+    assert torch.equal(y2, y) and torch.equal(u2, u) and torch.equal(v2, v)

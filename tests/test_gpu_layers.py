@@ -1,6 +1,9 @@
 """HIP conv kernels (through the C ABI) against the CPU oracle on the same seeded inputs.
 fp32 mode: bit-exact (the kernels use the oracle's fma order on the fp32-input MFMA);
-fp16 mode: fp16 storage / fp32 accumulate, compared with a stated tolerance."""
+fp16 mode: compared with the oracle's fp16-storage emulation (Net.dcb_f16 / Net.conv_f16: same packed
+weights, rounds to fp16 exactly where the kernels store, fp32 accumulate).  What is left between the two
+is the summation order inside the MFMA and the hardware exp2 / rcp, i.e. occasional one-ulp fp16 rounding
+flips that travel through the following layers: the bound below is a few fp16 ulps of the tensor's RMS."""
 import numpy as np
 import pytest
 import torch
@@ -9,7 +12,11 @@ import dcvc_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-F16_RTOL = 3e-2   # relative to the tensor's RMS: fp16 storage of every intermediate (11-bit mantissa)
+# fp16 mode vs the fp16-storage oracle: max |err| <= F16_MAX_RMS * rms and mean |err| <= F16_MEAN_RMS * rms
+# (one fp16 ulp is 2^-11 = 4.9e-4 relative; measured on MI355X: see tools/f16_err.py / profiles/r02_f16_err.json)
+F16_MAX_RMS = 6e-3
+F16_MEAN_RMS = 2e-4
+F16_STATS = {}   # what -> (max/rms, mean/rms), collected for tools/f16_err.py
 
 
 def _rng(seed):
@@ -46,8 +53,10 @@ def compare(got, ref, dtype, what):
         assert np.array_equal(got, ref), f"{what}: fp32 path not bit-exact, max|d|={np.abs(got - ref).max()}"
     else:
         rms = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2))) + 1e-6
-        err = float(np.abs(got.astype(np.float64) - ref).max())
-        assert err <= F16_RTOL * rms * 4, f"{what}: fp16 max err {err} vs rms {rms}"
+        d = np.abs(got.astype(np.float64) - ref)
+        F16_STATS[what] = (float(d.max()) / rms, float(d.mean()) / rms)
+        assert d.max() <= F16_MAX_RMS * rms, f"{what}: fp16 max err {d.max()} vs rms {rms} ({d.max() / rms:.2e})"
+        assert d.mean() <= F16_MEAN_RMS * rms, f"{what}: fp16 mean err {d.mean()} vs rms {rms} ({d.mean() / rms:.2e})"
 
 
 DCB_CASES = [
@@ -81,7 +90,8 @@ def test_depth_conv_block(case, dtype):
     q = rng.uniform(0.5, 1.5, c).astype(np.float32) if quant else None
     if dtype == torch.float16:   # the oracle sees the same fp16-rounded input
         x = x.astype(np.float16).astype(np.float32)
-    ref = O.Net(sd).dcb(x, "m", shortcut=shortcut, q=q)
+    net = O.Net(sd)
+    ref = (net.dcb_f16 if dtype == torch.float16 else net.dcb)(x, "m", shortcut=shortcut, q=q)
     blk = nn.DepthConvBlock(sd, "m", dtype, shortcut=shortcut)
     qd = torch.from_numpy(q).cuda() if quant else None
     if split:
@@ -106,7 +116,7 @@ def test_depth_conv_block_large_map_fp16(c):
     sd = make_dcb_weights(rng, "m", c, c, False)
     x = rng.standard_normal((H, W, c)).astype(np.float16).astype(np.float32)
     q = rng.uniform(0.5, 1.5, c).astype(np.float32)
-    ref = O.Net(sd).dcb(x, "m", shortcut=True, q=q)
+    ref = O.Net(sd).dcb_f16(x, "m", shortcut=True, q=q)
     blk = nn.DepthConvBlock(sd, "m", torch.float16, shortcut=True)
     out = blk(to_dev(x, blk.cin_p, torch.float16), quant=torch.from_numpy(q).cuda())
     torch.cuda.synchronize()
@@ -187,13 +197,18 @@ def test_conv(case, dtype):
     if dtype == torch.float16:
         x = x.astype(np.float16).astype(np.float32)
     q = rng.uniform(0.5, 1.5, cout).astype(np.float32)
-    ref = O.Net(sd).conv(x, "m", stride, pad)
-    if epi == "quant":
-        ref = ref * q
-    elif epi == "shuffle":
-        ref = O.pixel_shuffle(ref, 2)
-    elif epi == "wsilu":
-        ref = O.wsilu(ref)
+    if dtype == torch.float16:
+        ref = O.Net(sd).conv_f16(x, "m", stride, pad, epilogue=epi if epi in ("quant", "wsilu") else "bias", q=q)
+        if epi == "shuffle":
+            ref = O.pixel_shuffle(ref, 2)
+    else:
+        ref = O.Net(sd).conv(x, "m", stride, pad)
+        if epi == "quant":
+            ref = ref * q
+        elif epi == "shuffle":
+            ref = O.pixel_shuffle(ref, 2)
+        elif epi == "wsilu":
+            ref = O.wsilu(ref)
     conv = nn.Conv2d(sd, "m", dtype, stride, pad, EPI[epi])
     out = conv(to_dev(x, conv.cin_p, dtype), quant=torch.from_numpy(q).cuda() if epi == "quant" else None)
     torch.cuda.synchronize()

@@ -74,3 +74,70 @@ def test_one_rate_point_end_to_end(tmp_path):
     for fi in range(N):       # the written planes are rounded / truncated, the logged PSNR is not: within 0.1 dB
         assert abs(harness.calc_psnr(raw[fi, :H * W], rec[fi, :H * W]) - log["frame_psnr_y"][fi]) < 0.1
     assert 0 < log["ave_all_frame_psnr"] < 60 and log["ave_all_frame_msssim"] == 0      # (untrained synthetic weights: single-digit dB)
+
+
+def _nets(dtype):
+    import torch
+    from opendcvc_amd import weights
+    from opendcvc_amd.models import DMC, DMCI
+    nets = []
+    for cls, name in ((DMCI, "dmci"), (DMC, "dmc")):
+        m = cls()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.make_state_dict(name, 1234).items()})
+        m.to("cuda").eval()
+        m.update(0.12)
+        nets.append(m.half() if dtype == "fp16" else m)
+    return nets
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fp32", "fp16"])
+def test_qp_sweep_matches_reference_rd_points(tmp_path, golden_dir, mode):
+    """BASELINE.json configs[2]: the qp sweep {0, 21, 42, 63} of one YUV 4:2:0 file through harness.run_sweep against
+    the log the REFERENCE's own run_one_point_with_stream wrote for the same file and weights
+    (tests/golden/make_golden_sweep.py -> sweep.json): same keys in the same order; fp32: every frame's bits within
+    one byte (= bpp within 1e-4 at these stream sizes is byte-exactness) and PSNR within 1e-4 dB; fp16: bpp within
+    2 %, PSNR within 0.05 dB - against the reference's fp32 run and against its own fp16 (CPU) run."""
+    import hashlib
+    import sys
+    sys.path.insert(0, golden_dir)
+    from make_golden_sweep import write_yuv420
+    gold = json.load(open(os.path.join(golden_dir, "sweep.json")))
+    cfg = gold["config"]
+    W, H, N = cfg["width"], cfg["height"], cfg["frames"]
+    src = str(tmp_path / "seq.yuv")
+    write_yuv420(src, W, H, N, cfg["src_seed"])
+    assert hashlib.sha256(open(src, "rb").read()).hexdigest() == gold["src_sha256"]
+    logs = harness.run_sweep(lambda: _nets(mode), src, W, H, N, qp_i=cfg["qps"], bin_prefix=str(tmp_path / "o"),
+                             intra_period=cfg["intra_period"], reset_interval=cfg["reset_interval"], verbose_json=True)
+    assert list(logs.keys()) == cfg["qps"] == harness.sweep_qps(4)
+    exact = 0
+    for qp in cfg["qps"]:
+        got = logs[qp]
+        refs = [gold["fp32"][str(qp)]] + ([gold["fp16"][str(qp)]] if mode == "fp16" and "error" not in gold["fp16"] else [])
+        assert [k for k in got.keys() if k not in ("qp_i", "qp_p")] == refs[0]["keys"], "log schema differs from the reference's"
+        assert got["frame_type"] == refs[0]["log"]["frame_type"] and got["qp_i"] == qp
+        blob = open(tmp_path / f"o_q{qp}.bin", "rb").read()
+        assert sum(got["frame_bpp"]) * H * W == pytest.approx(8 * len(blob))
+        for ref in refs:
+            want = ref["log"]
+            for fi in range(N):
+                gb, wb = got["frame_bpp"][fi] * H * W, want["frame_bpp"][fi] * H * W
+                for k in ("frame_psnr", "frame_psnr_y", "frame_psnr_u", "frame_psnr_v"):
+                    tol = 1e-4 if mode == "fp32" else 0.05
+                    assert abs(got[k][fi] - want[k][fi]) < tol, (qp, fi, k, got[k][fi], want[k][fi])
+                if mode == "fp32":
+                    assert abs(gb - wb) <= 8, (qp, fi, gb, wb)
+                else:
+                    assert abs(gb - wb) <= 0.02 * wb + 8, (qp, fi, gb, wb)
+            for k in ("ave_i_frame_bpp", "ave_p_frame_bpp", "ave_all_frame_bpp"):
+                rel = 1e-3 if mode == "fp32" else 0.02
+                assert got[k] == pytest.approx(want[k], rel=rel), (qp, k)
+            for k in ("ave_i_frame_psnr", "ave_p_frame_psnr", "ave_all_frame_psnr", "ave_all_frame_psnr_y"):
+                assert abs(got[k] - want[k]) < (1e-4 if mode == "fp32" else 0.05), (qp, k)
+        exact += hashlib.sha256(blob).hexdigest() == refs[0]["bin_sha256"]
+    if mode == "fp32":      # whole containers byte-identical to the reference's .bin files (a flipped symbol may cost one)
+        assert exact >= len(cfg["qps"]) - 1, f"only {exact} of {len(cfg['qps'])} containers byte-identical"
+    out = os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump({str(k): v for k, v in logs.items()}, open(os.path.join(out, f"sweep_{mode}.json"), "w"), indent=1)
