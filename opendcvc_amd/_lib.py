@@ -12,7 +12,9 @@ from ctypes import (POINTER, c_char_p, c_float, c_int, c_int8, c_int16, c_int32,
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DCVC_AMD_DIAG=1 selects the developer build with in-kernel diagnostics (make -C opendcvc_amd/csrc diag)
-LIB_PATH = os.path.join(_HERE, "libdcvc_amd_diag.so" if os.environ.get("DCVC_AMD_DIAG") else "libdcvc_amd.so")
+# DCVC_AMD_LIB=<file name in this directory> selects an experimental build (kernel A/B measurements)
+LIB_PATH = os.path.join(_HERE, os.environ.get("DCVC_AMD_LIB") or
+                        ("libdcvc_amd_diag.so" if os.environ.get("DCVC_AMD_DIAG") else "libdcvc_amd.so"))
 
 F16, F32 = 0, 1
 EPI_BIAS, EPI_BIAS_QUANT, EPI_SHUFFLE2, EPI_WSILU = 0, 1, 2, 3

@@ -13,6 +13,12 @@
 
 #include "common.hpp"
 #include "gemm_core.hpp"
+// Experimental pixel-stationary DepthConvBlock tail (dcb_ps.hpp): compiled into the developer build only
+// (make diag: -DDCVC_DIAG -DDCVC_EXPERIMENTAL_PS, selected at run time with DCVC_PS=1).  It is correct (same tests)
+// but measured slower than the channel-split tails below - DESIGN.md section 4 has the numbers and the analysis.
+#ifdef DCVC_EXPERIMENTAL_PS
+#include "dcb_ps.hpp"
+#endif
 
 namespace {
 
@@ -774,11 +780,27 @@ int upload_T(DevBuf& dst, int n, const std::function<float(int)>& get)
     return dst.upload(v.data(), v.size() * sizeof(T));
 }
 
+#ifdef DCVC_EXPERIMENTAL_PS
+// ---- pixel-stationary tail: packing (dcb_ps.hpp) -------------------------------------------------------
+// one 1 KiB A fragment of v_mfma_f32_32x32x16_f16: lane l holds W[row0 + sigma(l & 31)][k0 + 8 (l >> 5) + j], j = 0..7
+inline void ps_put_frag(std::vector<half_t>& buf, const std::function<float(int, int)>& get, int row0, int k0)
+{
+    for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) buf.push_back((half_t)get(row0 + ps::sigma(l & 31), k0 + 8 * (l >> 5) + j));
+}
+
+inline bool ps_width_ok(int c_p) { return c_p == 256; }   // (320 / 384: register budget)
+#endif
+
 }  // namespace
 
 struct dcvc_dcb {
     int dtype, cin, c, cin_p, c_p, shortcut, adapt;
     DevBuf wa, ba, w1, b1, wd, bd, w2, b2, w3, b3, w4, b4;
+    // pixel-stationary tail (dcb_ps.hpp; fp16, widths 256 / 320 / 384): the tail's weights in consumption order,
+    // this block's first conv in the same form (for the previous block's fused head), and the small tables
+    int ps = 0;
+    DevBuf ps_tail, ps_head, ps_tbl;
 };
 
 struct dcvc_conv {
@@ -830,6 +852,62 @@ int set_lds(K kernel, size_t bytes)
     }
     return 0;
 }
+
+#ifdef DCVC_EXPERIMENTAL_PS
+template <int C>
+int launch_tail_ps(const ps::Params& pp, int H, int W, hipStream_t st)
+{
+    const int grid = ((H + ps::TH - 1) / ps::TH) * ((W + ps::TW - 1) / ps::TW);
+    const size_t lds = ps::Cfg<C>::LDS_BYTES;
+    int rc = set_lds(ps::dcb_tail_ps_kernel<C>, lds);
+    if (rc) return rc;
+#ifdef DCVC_DIAG
+    static const bool want_stamps = getenv("DCVC_STAMPS") != nullptr;
+    if (want_stamps) {   // developer build only: median cycles per phase over the workgroups
+        ps::Params q = pp;
+        DCVC_HIP(hipMalloc(&q.stamps, (size_t)grid * 8 * sizeof(unsigned long long)));
+        hipLaunchKernelGGL((ps::dcb_tail_ps_kernel<C>), dim3(grid), dim3(ps::NTHR), lds, st, q);
+        DCVC_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> hs((size_t)grid * 8);
+        DCVC_HIP(hipMemcpy(hs.data(), q.stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(q.stamps);
+        static int printed = 0;
+        if (printed++ % 16 == 15) {
+            const char* names[7] = {"prologue", "gemm2+dw", "o", "ffn", "r", "store", "head"};
+            unsigned long long t0 = ~0ull, t1 = 0;
+            fprintf(stderr, "[ps stamps C=%d grid=%d]", C, grid);
+            for (int k = 0; k < 7; ++k) {
+                std::vector<unsigned long long> v(grid);
+                for (int b = 0; b < grid; ++b) v[b] = hs[(size_t)b * 8 + k + 1] - hs[(size_t)b * 8 + k];
+                std::sort(v.begin(), v.end());
+                fprintf(stderr, " %s=%llu", names[k], v[grid / 2]);
+            }
+            std::vector<unsigned long long> st0(grid), tot(grid);
+            for (int b = 0; b < grid; ++b) {
+                t0 = std::min(t0, hs[(size_t)b * 8]);
+                t1 = std::max(t1, hs[(size_t)b * 8 + 7]);
+                tot[b] = hs[(size_t)b * 8 + 7] - hs[(size_t)b * 8];
+            }
+            for (int b = 0; b < grid; ++b) st0[b] = hs[(size_t)b * 8] - t0;
+            std::sort(st0.begin(), st0.end());
+            std::sort(tot.begin(), tot.end());
+            fprintf(stderr, " | total med %llu max %llu span %llu start med %llu max %llu\n", tot[grid / 2], tot[grid - 1],
+                    t1 - t0, st0[grid / 2], st0[grid - 1]);
+        }
+        return 0;
+    }
+#endif
+    hipLaunchKernelGGL((ps::dcb_tail_ps_kernel<C>), dim3(grid), dim3(ps::NTHR), lds, st, pp);
+    return 0;
+}
+
+// maps that give every CU a 128-pixel tile (136 x 240: 255 tiles); developer build only, DCVC_PS=1 selects it
+static bool use_ps(const dcvc_dcb* h, int H, int W)
+{
+    static const int env = getenv("DCVC_PS") ? atoi(getenv("DCVC_PS")) : 0;
+    return env != 0 && h->ps && (long)H * W >= 12000;
+}
+#endif
 
 // chained launches: this block's `a` lives in scratch slot a_slot (already there if head_done: the previous
 // block's tail produced it); if next != NULL this block's tail also produces next's `a` in the other slot
@@ -917,6 +995,42 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         tp.na_out = a_next;
         tp.nlda = C;
     }
+#ifdef DCVC_EXPERIMENTAL_PS
+    if constexpr (sizeof(T) == 2) {
+        if (use_ps(h, H, W) && (!ch.next || ch.next->ps)) {
+            ps::Params pp{};
+            pp.a = tp.a;
+            pp.lda = tp.lda;
+            pp.ident = tp.ident;
+            pp.ldi = tp.ldi;
+            pp.H = H;
+            pp.W = W;
+            pp.c_log = h->c;
+            pp.stream = h->ps_tail.p;
+            pp.tables = h->ps_tbl.p;
+            pp.shortcut = h->shortcut;
+            pp.q = quant;
+            pp.out = out;
+            pp.ldo = ldo;
+            if (ch.next) {
+                pp.nstream = ch.next->ps_head.p;
+                pp.nb1 = (const float*)ch.next->b1.p;
+                pp.na_out = a_next;
+                pp.nlda = C;
+            }
+            int rc = dcvc::E_ARG;
+            switch (C) {
+            case 256: rc = launch_tail_ps<256>(pp, H, W, st); break;
+            default: dcvc::set_error("pixel-stationary tail: width %d not instantiated", C); break;
+            }
+            if (rc) return rc;
+            DCVC_LAUNCH_CHECK();
+            if (ev) DCVC_HIP(hipEventRecord(ev[2], st));
+            return 0;
+        }
+    }
+#endif
+#ifdef DCVC_DIAG      // developer build only (make diag): phase ablation / in-kernel stamps
     {
         static const int abl = getenv("DCVC_ABLATE") ? atoi(getenv("DCVC_ABLATE")) : 0;
         tp.ablate = abl;
@@ -927,6 +1041,7 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         DCVC_HIP(hipMalloc(&d_stamps, (size_t)grid * 8 * sizeof(unsigned long long)));
         tp.stamps = d_stamps;
     }
+#endif
     {
         // Widths of 384 and up (6+ channel tiles per wave) fit one workgroup per CU only.  Eight waves
         // (two per SIMD, half the channel tiles each, <= 256 VGPRs) give every SIMD a second wave of the
@@ -943,6 +1058,7 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     }
     DCVC_LAUNCH_CHECK();
     if (ev) DCVC_HIP(hipEventRecord(ev[2], st));
+#ifdef DCVC_DIAG
     if (want_stamps) {   // diagnostic only: median cycles per phase over the workgroups
         DCVC_HIP(hipStreamSynchronize(st));
         std::vector<unsigned long long> hs((size_t)grid * 8);
@@ -980,6 +1096,7 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
             }
         }
     }
+#endif
     return 0;
 }
 
@@ -1044,11 +1161,13 @@ int dispatch_conv(const dcvc_conv* h, const ConvParams& cp, hipStream_t st)
 // Pixel-tile selection (f16): 16*MT pixels per workgroup.  Small feature maps take 32-pixel tiles so
 // that the grid still covers the 256 CUs (measured: 68x120 maps 15-25 % faster); 128-pixel tiles
 // (MT = 8, one workgroup per CU) were measured slower than 64-pixel tiles at two workgroups per CU
-// (80 vs 63 us at C = 256, 136x240) and are not instantiated.  DCVC_MT overrides for experiments.
+// (80 vs 63 us at C = 256, 136x240) and are not instantiated.  (Developer build: DCVC_MT overrides.)
 static int pick_mt_f16(int H, int W, int c_p)
 {
+#ifdef DCVC_DIAG
     static const int forced = getenv("DCVC_MT") ? atoi(getenv("DCVC_MT")) : 0;
     if (forced == 2 || forced == 4) return forced;
+#endif
     const long P = (long)H * W;
     (void)c_p;
     return P >= 12000 ? 4 : 2;
@@ -1122,6 +1241,47 @@ int dcvc_dcb_create(int dtype, int cin, int c, int shortcut, const float* adapto
     rc |= upload_f32(h->b3, 4 * Cp, [&](int n) { const int rr = u_row(n); return rr >= 0 ? ka * b3[rr] : 0.f; });
     rc |= pack_any(dtype, h->w4, Cp, 2 * Cp, [&](int n, int k) { return (n < C && k < 2 * C) ? w4[(size_t)n * 2 * C + k] / ka : 0.f; });
     rc |= upload_f32(h->b4, Cp, [&](int n) { return n < C ? b4[n] : 0.f; });
+#ifdef DCVC_EXPERIMENTAL_PS
+    if (rc == 0 && dtype == DCVC_F16 && ps_width_ok(Cp)) {
+        // the same (pre-scaled, fp16) weights once more, as the fragment stream of dcb_tail_ps_kernel
+        const int NT = Cp / 32, KS = Cp / 16;
+        auto W1 = [&](int n, int k) { return (n < C && k < C) ? ka * w1[(size_t)n * C + k] : 0.f; };
+        auto W2 = [&](int n, int k) { return (n < C && k < C) ? w2[(size_t)n * C + k] : 0.f; };
+        auto W3 = [&](int n, int k) { const int rr = u_row(n); return (rr >= 0 && k < C) ? ka * w3[(size_t)rr * C + k] : 0.f; };
+        auto W4 = [&](int n, int k) { return (n < C && k < 2 * C) ? w4[(size_t)n * 2 * C + k] / ka : 0.f; };
+        std::vector<half_t> st;
+        st.reserve((size_t)7 * Cp * Cp);
+        for (int i = 0; i < NT; ++i)                       // W2, k-outer: slot i = k-steps 2 i, 2 i + 1
+            for (int kk = 0; kk < 2; ++kk)
+                for (int t = 0; t < NT; ++t) ps_put_frag(st, W2, 32 * t, 16 * (2 * i + kk));
+        auto put_u = [&](int j) {                          // W3: u_lo tile j, u_hi tile j (one slot each)
+            for (int half = 0; half < 2; ++half)
+                for (int ks = 0; ks < KS; ++ks) ps_put_frag(st, W3, half * 2 * Cp + 32 * j, 16 * ks);
+        };
+        put_u(0);
+        for (int j = 0; j < KS; ++j) {
+            if (j + 1 < KS) put_u(j + 1);
+            for (int s2 = 0; s2 < 2; ++s2)                 // W4 slice of v tile j: k = 32 j + 16 s
+                for (int t = 0; t < NT; ++t) ps_put_frag(st, W4, 32 * t, 32 * j + 16 * s2);
+        }
+        rc |= h->ps_tail.upload(st.data(), st.size() * sizeof(half_t));
+        std::vector<half_t> hd;
+        for (int t = 0; t < NT; ++t)                       // W1, tile-outer
+            for (int ks = 0; ks < KS; ++ks) ps_put_frag(hd, W1, 32 * t, 16 * ks);
+        rc |= h->ps_head.upload(hd.data(), hd.size() * sizeof(half_t));
+        // tables: wd [9][Cp] f16 | bd | b2 | b3 [4 Cp] | b4   (fp32)
+        std::vector<char> tb((size_t)46 * Cp);
+        half_t* twd = reinterpret_cast<half_t*>(tb.data());
+        for (int i = 0; i < 9 * Cp; ++i) twd[i] = (half_t)dwget(i);
+        float* tf = reinterpret_cast<float*>(tb.data() + 18 * Cp);
+        for (int n = 0; n < Cp; ++n) tf[n] = n < C ? bd[n] : 0.f;
+        for (int n = 0; n < Cp; ++n) tf[Cp + n] = n < C ? b2[n] : 0.f;
+        for (int n = 0; n < 4 * Cp; ++n) { const int rr = u_row(n); tf[2 * Cp + n] = rr >= 0 ? ka * b3[rr] : 0.f; }
+        for (int n = 0; n < Cp; ++n) tf[6 * Cp + n] = n < C ? b4[n] : 0.f;
+        rc |= h->ps_tbl.upload(tb.data(), tb.size());
+        h->ps = rc == 0;
+    }
+#endif
     if (rc) return rc < 0 ? rc : dcvc::E_MEM;
     *out = h.release();
     return 0;

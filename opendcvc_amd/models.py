@@ -182,6 +182,7 @@ class CompressionModel(tnn.Module):
             _register(self, name, init)
         self.entropy_coder = None
         self.force_zero_thres = None
+        self._z_master = None
         self._layers = None
         self._layers_key = None
         self._q = {}
@@ -217,7 +218,22 @@ class CompressionModel(tnn.Module):
         sd = self.state_dict()
         pre = "bit_estimator_z."
         params = {k[len(pre):]: v.detach().float().cpu() for k, v in sd.items() if k.startswith(pre)}
+        params.update(self._z_master or {})       # fp32 values saved by half(): same tables before and after half()
         self._z_group = self.entropy_coder.add_cdf(*entropy.factorized_cdf_tables(params, self.qp_total, self.z_channel))
+
+    def half(self):
+        """The CDF tables of the z prior define the bit stream: they are always built from the fp32 parameters
+        (the reference builds them in update() before .half(), test_video.py:398-404); a copy of those parameters
+        survives the conversion, so update() may be called again afterwards and still gives the same tables."""
+        pre = "bit_estimator_z."
+        if self._z_master is None and next(self.parameters()).dtype == torch.float32:
+            self._z_master = {k[len(pre):]: v.detach().float().cpu().clone() for k, v in self.state_dict().items()
+                              if k.startswith(pre)}
+        return super().half()
+
+    def load_state_dict(self, *args, **kwargs):
+        self._z_master = None
+        return super().load_state_dict(*args, **kwargs)
 
     def set_use_two_entropy_coders(self, use_two_entropy_coders):
         self.entropy_coder.set_use_two_entropy_coders(use_two_entropy_coders)

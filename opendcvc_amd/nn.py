@@ -55,15 +55,21 @@ def _geom(x):
 
 
 class Scratch:
-    """Grow-only device scratch per (device, stream): no allocation in the steady state."""
+    """Grow-only device scratch per (device, stream): no allocation in the steady state.  A buffer that has been
+    handed out is never freed: captured HIP graphs (models.GraphCache) keep its raw address in their kernel
+    arguments, so when a larger map needs a larger scratch the old one is retired, not released (sizes grow
+    geometrically, the retired total stays below the largest buffer)."""
     _pool = {}
+    _retired = []
 
     @classmethod
     def get(cls, nbytes, device):
         key = (str(device), torch.cuda.current_stream().cuda_stream)
         buf = cls._pool.get(key)
         if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+            if buf is not None:
+                cls._retired.append(buf)
+            buf = torch.empty(int(nbytes * 2) + 256, dtype=torch.uint8, device=device)
             cls._pool[key] = buf
         return buf
 
