@@ -8,17 +8,23 @@ One step = one frame of a 32-frame-GOP 1080p sequence (configs[1]) ENCODED and D
 path (fp16 storage / fp32 accumulate, like the reference's published numbers), including the host
 rANS coding, with the padded input frames already resident in HBM.  The timed region runs the
 encoder and the decoder as a two-stage pipeline (two host threads, two HIP streams on the same GPU:
-frame n decodes while frame n+1 encodes); after it, the same frames are run one direction at a time
-for the per-direction fps (`enc_fps_per_gpu`, `dec_fps_per_gpu`, `sequential_*`), which is how the
-reference times them and what `vs_baseline` compares.  With N > 1 every rank
+frame n decodes while frame n+1 encodes).  Whatever --steps is, the timed window carries I frames at
+(at least) the GOP's rate: the window is placed in the GOP so that an I frame falls inside it
+(steps < 32: one I frame in the middle, i.e. MORE than the 1-in-32 share; whole GOPs otherwise) - the
+frames needed to get there are extra untimed warm-up (`config.alignment_frames`).  After the timed
+region one whole GOP is run one direction at a time for the per-direction fps (`enc_fps_per_gpu`,
+`dec_fps_per_gpu`, `sequential_*`), which is how the reference times them and what `vs_baseline`
+compares, and for bpp / PSNR (per plane and (6Y+U+V)/8, against the 8-bit source planes, the
+reference's get_distortion).  With N > 1 every rank
 codes its own independent stream (weak scaling, no data-path collective; the weights are
 broadcast once from rank 0 over RCCL).  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
   roofline     dominant kernel (dcb_tail_kernel<f16>, C = 256 at 136x240): algorithmic FLOP per
                launch / HIP-event time on its stream, against the 2.5 PFLOP/s dense f16 MFMA peak.
-  cpu_baseline the CPU oracle (port of the reference's torch fallback path) timed on the host
-               cores on a bounded sample (one 1080p P frame, encode + decode).
+  cpu_baseline the CPU oracle (port of the reference's torch fallback path) on the host cores: P frames of a
+               1/16-area crop (480x272), 2 warm-up + 3 timed frames, at 1 thread (what the reference harness
+               pins, src/utils/common.py:23) and at all cores, scaled to 1080p by the pixel ratio.
 """
 import argparse
 import ctypes
@@ -37,7 +43,8 @@ from opendcvc_amd import _lib, weights  # noqa: E402
 from opendcvc_amd import dist as dist_utils  # noqa: E402
 from opendcvc_amd import nn as L  # noqa: E402
 from opendcvc_amd.models import DMC, DMCI  # noqa: E402
-from opendcvc_amd.pipeline import EncodeDecodePipeline, SequenceDecoder, SequenceEncoder, use_two_entropy_coders  # noqa: E402
+from opendcvc_amd.pipeline import (EncodeDecodePipeline, SequenceDecoder, SequenceEncoder, load_yuv420_frame,  # noqa: E402
+                                   use_two_entropy_coders)
 
 HEIGHT, WIDTH = 1080, 1920
 GOP = 32
@@ -66,13 +73,15 @@ def load_models(dtype, device, world, rank):
 
 
 def make_frames(seed, dtype, device):
-    pr, pb = DMCI.get_padding_size(HEIGHT, WIDTH, 16)
-    frames = []
+    """One GOP of synthetic planar 8-bit YUV 4:2:0 frames (SURVEY 8d recipe), uploaded once: the uint8 planes (kept
+    for the PSNR) and the padded model inputs made from them by the fused loader kernel (get_src_frame +
+    replicate_pad of the reference, test_video.py:74-91,179)."""
+    planes, frames = [], []
     for fi in range(GOP):
-        x = weights.synthetic_frame_yuv444(HEIGHT, WIDTH, fi, seed)
-        x = np.pad(x, ((0, 0), (0, 0), (0, pb), (0, pr)), mode="edge")
-        frames.append(torch.from_numpy(x).to(device=device, dtype=dtype))
-    return frames
+        yuv = [torch.from_numpy(a).to(device) for a in weights.synthetic_frame_yuv420(HEIGHT, WIDTH, fi, seed)]
+        planes.append(yuv)
+        frames.append(load_yuv420_frame(yuv[0], yuv[1], yuv[2], dtype))
+    return planes, frames
 
 
 def roofline_leg(p_net, device, dtype):
@@ -105,31 +114,57 @@ def roofline_leg(p_net, device, dtype):
             "head_kernel_ms": round(head.value, 4)}
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline_leg():
-    """The oracle (CPU port of the reference path) on one 1080p P frame, encode + decode."""
-    ncores = min(len(os.sched_getaffinity(0)), 32)
-    os.environ["OMP_NUM_THREADS"] = str(ncores)      # read by libgomp when the oracle library loads
+    """The oracle (CPU port of the reference path, fp32) on P frames of a 480x272 crop: warm-up (2 frames; 1 in the
+    single-thread leg) + 3 timed frames (encode + decode each) at 1 thread and at all cores, frames/s
+    scaled to the 1080p pixel count."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import dcvc_oracle as O
-    pr, pb = DMCI.get_padding_size(HEIGHT, WIDTH, 16)
-    pad = lambda a: np.pad(a, ((0, 0), (0, 0), (0, pb), (0, pr)), mode="edge")
-    x0 = pad(weights.synthetic_frame_yuv444(HEIGHT, WIDTH, 0, 0))
-    x1 = pad(weights.synthetic_frame_yuv444(HEIGHT, WIDTH, 1, 0))
-    p = O.OracleDMC(weights.make_state_dict("dmc", 1234))
-    p.update(THRES)
-    p.set_use_two_entropy_coders(True)
-    p.clear_dpb()
-    p.add_ref_frame(None, x0)
-    t0 = time.perf_counter()
-    enc = p.compress(x1, QP)
-    t1 = time.perf_counter()
-    p.clear_dpb()
-    p.add_ref_frame(None, x0)
-    p.decompress(enc["bit_stream"], dict(height=HEIGHT, width=WIDTH, ec_part=1, use_ada_i=0), QP)
-    t2 = time.perf_counter()
-    return {"value": round(1.0 / (t2 - t0), 4), "unit": "frames/s", "cores": ncores, "kind": "port",
-            "sample": "one 1080p (1088x1920 padded) P frame, encode %.2f s + decode %.2f s, fp32 C/OpenMP oracle"
-                      % (t1 - t0, t2 - t1)}
+    O.lib()
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+    except OSError:
+        gomp = None
+    ncores = len(os.sched_getaffinity(0))
+    h, w = 272, 480
+    scale = (h * w) / float((HEIGHT + (-HEIGHT) % 16) * (WIDTH + (-WIDTH) % 16))
+    frames = [weights.synthetic_frame_yuv444(h, w, fi, 0) for fi in range(6)]
+    sps = dict(height=h, width=w, ec_part=0, use_ada_i=0)
+    out = {}
+    for label, nt in (("one_thread", 1), ("all_cores", ncores)):
+        if gomp is not None:
+            gomp.omp_set_num_threads(nt)
+        enc_net = O.OracleDMC(weights.make_state_dict("dmc", 1234))
+        dec_net = O.OracleDMC(weights.make_state_dict("dmc", 1234))
+        for m in (enc_net, dec_net):
+            m.update(THRES)
+            m.set_use_two_entropy_coders(False)
+            m.clear_dpb()
+            m.add_ref_frame(None, frames[0])
+        times = []
+        warm = 1 if nt == 1 and ncores > 1 else 2          # (the single-thread leg is ~5 s per frame: one warm-up there)
+        for fi in range(1, warm + 4):
+            t0 = time.perf_counter()
+            e = enc_net.compress(frames[fi], QP)
+            dec_net.decompress(e["bit_stream"], sps, QP)
+            times.append(time.perf_counter() - t0)
+        out[label] = scale * 3.0 / sum(times[warm:])
+        if nt == ncores:
+            break
+    return {"value": round(out.get("all_cores", out["one_thread"]), 4), "unit": "frames/s", "cores": ncores, "kind": "port",
+            "one_thread_value": round(out["one_thread"], 5), "cpu_model": cpu_model(),
+            "sample": "P frames of a 480x272 crop of the same synthetic sequence (1/16 of the padded 1080p area), warm-up + 3 "
+                      "timed frames per leg, encode + decode, fp32 C/OpenMP oracle; frames/s scaled by the pixel ratio"}
 
 
 def main():
@@ -166,30 +201,13 @@ def main():
         pe._ensure_layers()
         print(json.dumps({"roofline": roofline_leg(pe, device, dtype)}), flush=True)
         return
-    frames = make_frames(rank, dtype, device)
+    planes, frames = make_frames(rank, dtype, device)
     enc = SequenceEncoder(ie, pe, QP, intra_period=GOP, reset_interval=GOP)
     # decoder output deferred by one frame: the reconstruction network of frame n runs in the host-decoding gaps
     # of frame n+1 (opendcvc_amd/pipeline.py); every timed frame is still completed inside the timed region (flush)
     dec = SequenceDecoder(idec, pdec, HEIGHT, WIDTH, two, defer_output=True)
 
-    state = {"i": 0, "t_enc": 0.0, "t_dec": 0.0, "bytes": 0, "n_i": 0, "j": 0}
-
-    def step_sequential():
-        """encode, wait, decode, wait - used for the per-direction fps (how the reference times them)"""
-        x = frames[state["i"] % GOP]
-        state["i"] += 1
-        t0 = time.perf_counter()
-        with torch.cuda.stream(s_enc):
-            pkt = enc.encode(x)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        with torch.cuda.stream(s_dec):
-            dec.decode(pkt)
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        state["t_enc"] += t1 - t0
-        state["t_dec"] += t2 - t1
-
+    state = {"i": 0, "t_enc": 0.0, "t_dec": 0.0, "bytes": 0, "n_i": 0, "j": 0, "seq_bytes": 0, "psnr": []}
     pipe = EncodeDecodePipeline(enc, dec, device)
     s_enc, s_dec = pipe.enc_stream, pipe.dec_stream
 
@@ -214,27 +232,56 @@ def main():
         dist_utils.barrier(world)
         torch.cuda.synchronize()
 
+    # Placement of the timed window in the GOP (the encoder codes an I frame whenever its frame counter is a multiple
+    # of 32): whole GOPs start on an I frame; a shorter window gets one I frame in its middle - never a P-only window.
+    K = args.steps
+    start = (GOP - (K % GOP) // 2) % GOP
+    align = (start - args.warmup) % GOP
     torch.cuda.synchronize()
-    run_pipelined(args.warmup, False)
+    run_pipelined(args.warmup + align, False)
+    assert state["i"] % GOP == start
     barrier()
     t0 = time.perf_counter()
-    run_pipelined(args.steps, True)
+    run_pipelined(K, True)
     barrier()
     elapsed = dist_utils.max_over_ranks(time.perf_counter() - t0, device, world)
-    assert state["j"] == args.warmup + args.steps
+    assert state["j"] == args.warmup + align + K
+    assert state["n_i"] >= max(1, K // GOP), "the timed window must contain I frames at the GOP's rate"
 
-    # outside the timed region: the same frames one direction at a time
-    n_seq = min(args.steps, GOP)
+    # outside the timed region: ONE WHOLE GOP (I frame first) one direction at a time, like the reference times them;
+    # bpp and PSNR of that GOP
+    from opendcvc_amd.harness import yuv420_distortion
+    run_pipelined((-state["i"]) % GOP, False)
+    assert state["i"] % GOP == 0
+    n_seq = GOP
+    pending = []                                    # the decoder emits P pictures one call late
     t_seq0 = time.perf_counter()
-    for _ in range(n_seq):
-        step_sequential()
+    for k in range(n_seq):
+        x = frames[k]
+        state["i"] += 1
+        ta = time.perf_counter()
+        with torch.cuda.stream(s_enc):
+            pkt = enc.encode(x)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        with torch.cuda.stream(s_dec):
+            pending += dec.decode(pkt)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        state["t_enc"] += tb - ta
+        state["t_dec"] += tc - tb
+        state["seq_bytes"] += len(pkt.bit_stream)
     with torch.cuda.stream(s_dec):
-        dec.flush()
+        pending += dec.flush()
     torch.cuda.synchronize()
     t_seq = time.perf_counter() - t_seq0
+    assert len(pending) == n_seq
+    for k, x_hat in enumerate(pending):             # (not timed) the reference's per-plane PSNR on the 8-bit planes
+        state["psnr"].append(yuv420_distortion(x_hat, *planes[k]))
+    psnr = np.mean(np.asarray(state["psnr"], np.float64), axis=0)
 
     if rank == 0:
-        K, N = args.steps, world
+        N = world
         value = N * K / elapsed
         seq_value = n_seq / t_seq                   # this rank, encode then decode one after the other
         if (WIDTH, HEIGHT) == (3840, 2160):       # README complexity table, A100 fp16 at 4K: 35.5 / 29.5 fps
@@ -250,6 +297,8 @@ def main():
             "config": {"workload": "DCVC-RT inter-coding, %s YUV420 32-frame GOP, single q (qp 32), one stream per MI355X "
                                    "(BASELINE.json configs[%d])" % (("1080p", 1) if (WIDTH, HEIGHT) == (1920, 1080) else (args.frame, 3)),
                        "frame": "%dx%d padded to %dx%d" % (WIDTH, HEIGHT, WIDTH + (-WIDTH) % 16, HEIGHT + (-HEIGHT) % 16), "intra_period": GOP, "i_frames_timed": state["n_i"],
+                       "i_frame_share_timed": round(state["n_i"] / float(K), 4), "i_frame_share_gop": round(1.0 / GOP, 4),
+                       "alignment_frames": align,
                        "entropy_coders": 2 if two else 1, "force_zero_thres": THRES,
                        "weights": "synthetic seed 1234 (opendcvc_amd/weights.py)",
                        "pipeline": "encoder and decoder on two host threads / two HIP streams of the same GPU: frame n "
@@ -261,6 +310,12 @@ def main():
             "sequential_fps_per_gpu": round(seq_value, 3), "sequential_ms_per_step": round(1e3 * t_seq / n_seq, 3),
             "enc_fps_per_gpu": round(n_seq / state["t_enc"], 2), "dec_fps_per_gpu": round(n_seq / state["t_dec"], 2),
             "bpp": round(state["bytes"] * 8.0 / (K * HEIGHT * WIDTH), 5),
+            "gop_bpp": round(state["seq_bytes"] * 8.0 / (n_seq * HEIGHT * WIDTH), 5),
+            "psnr": {"weighted_6y_u_v": round(float(psnr[0]), 4), "y": round(float(psnr[1]), 4), "u": round(float(psnr[2]), 4),
+                     "v": round(float(psnr[3]), 4),
+                     "note": "mean over one GOP, decoded vs the 8-bit source planes (reference get_distortion, "
+                             "test_video.py:94-111); synthetic untrained weights: single-digit dB by construction - the "
+                             "number pins parity with the reference (tests/golden), not picture quality"},
         }
         # whole-frame fractions (conv-hook GFLOP and fused-unit algorithmic bytes of a steady P frame at
         # 1088x1920, scaled by the padded pixel count) from the per-direction times of the sequential pass

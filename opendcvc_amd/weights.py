@@ -93,3 +93,12 @@ def synthetic_frame_yuv444(height, width, frame_idx=0, seed=0):
     V = np.repeat(np.repeat(V, 2, axis=0), 2, axis=1)[:height, :width]
     x = np.stack([Y, U, V], axis=0)[None].astype(np.float32) / np.float32(255.0)
     return np.ascontiguousarray(x)
+
+
+def synthetic_frame_yuv420(height, width, frame_idx=0, seed=0):
+    """The same synthetic frame as planar 8-bit YUV 4:2:0 (uint8 Y [H,W], U, V [H/2,W/2]) - the form the reference
+    reads from disk (src/utils/video_reader.py:50-90).  synthetic_frame_yuv444 is exactly this frame after the
+    reference's nearest chroma upsampling and /255."""
+    x = synthetic_frame_yuv444(height, width, frame_idx, seed)[0]
+    q = np.clip(np.rint(x * np.float32(255.0)), 0, 255).astype(np.uint8)
+    return q[0], np.ascontiguousarray(q[1, ::2, ::2]), np.ascontiguousarray(q[2, ::2, ::2])
