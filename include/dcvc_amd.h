@@ -223,6 +223,8 @@ void dcvc_rans_enc_destroy(dcvc_rans_enc*);
 /* cdf [n][stride] int32, sizes [n], offsets [n] -> group index (add_cdf, py_rans.cpp:69-95) */
 int dcvc_rans_enc_add_cdf(dcvc_rans_enc*, const int32_t* cdf, int n, int stride,
                           const int32_t* sizes, const int32_t* offsets);
+/* forgets every table group; the next add_cdf returns 0 again (empty_cdf_buffer, py_rans.cpp:97-101) */
+int dcvc_rans_enc_empty_cdf(dcvc_rans_enc*);
 void dcvc_rans_enc_set_use_two(dcvc_rans_enc*, int two);
 int dcvc_rans_enc_reset(dcvc_rans_enc*);
 /* symbols: (int8 symbol << 8) + uint8 cdf index (encode_y, py_rans.cpp:20-41).
@@ -241,6 +243,7 @@ dcvc_rans_dec* dcvc_rans_dec_create(void);
 void dcvc_rans_dec_destroy(dcvc_rans_dec*);
 int dcvc_rans_dec_add_cdf(dcvc_rans_dec*, const int32_t* cdf, int n, int stride,
                           const int32_t* sizes, const int32_t* offsets);
+int dcvc_rans_dec_empty_cdf(dcvc_rans_dec*);   /* py_rans.cpp:291-295 */
 void dcvc_rans_dec_set_use_two(dcvc_rans_dec*, int two);
 int dcvc_rans_dec_set_stream(dcvc_rans_dec*, const uint8_t* data, int64_t n);
 /* indexes: uint8 cdf index per symbol, 0xFF = skipped (decodes nothing, yields 0).

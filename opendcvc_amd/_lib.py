@@ -84,6 +84,7 @@ _SIGS = {
     "dcvc_rans_enc_create": (_P, []),
     "dcvc_rans_enc_destroy": (None, [_P]),
     "dcvc_rans_enc_add_cdf": (_I, [_P, _P, _I, _I, _P, _P]),
+    "dcvc_rans_enc_empty_cdf": (_I, [_P]),
     "dcvc_rans_enc_set_use_two": (None, [_P, _I]),
     "dcvc_rans_enc_reset": (_I, [_P]),
     "dcvc_rans_enc_encode_y": (_I, [_P, _P, _L, _I]),
@@ -94,6 +95,7 @@ _SIGS = {
     "dcvc_rans_dec_create": (_P, []),
     "dcvc_rans_dec_destroy": (None, [_P]),
     "dcvc_rans_dec_add_cdf": (_I, [_P, _P, _I, _I, _P, _P]),
+    "dcvc_rans_dec_empty_cdf": (_I, [_P]),
     "dcvc_rans_dec_set_use_two": (None, [_P, _I]),
     "dcvc_rans_dec_set_stream": (_I, [_P, _P, _L]),
     "dcvc_rans_dec_decode_y": (_I, [_P, _P, _L, _I]),

@@ -588,6 +588,15 @@ int dcvc_rans_enc_add_cdf(dcvc_rans_enc* e, const int32_t* cdf, int n, int strid
     return add_group(e->groups, cdf, n, stride, sizes, offsets);
 }
 
+int dcvc_rans_enc_empty_cdf(dcvc_rans_enc* e)
+{
+    DCVC_REQUIRE(e, "dcvc_rans_enc_empty_cdf: null coder");
+    e->worker[0].wait_idle();
+    e->worker[1].wait_idle();
+    e->groups.clear();
+    return 0;
+}
+
 void dcvc_rans_enc_set_use_two(dcvc_rans_enc* e, int two)
 {
     if (e) e->two = two != 0;
@@ -739,6 +748,15 @@ int dcvc_rans_dec_add_cdf(dcvc_rans_dec* d, const int32_t* cdf, int n, int strid
 {
     DCVC_REQUIRE(d, "dcvc_rans_dec_add_cdf: null coder");
     return add_group(d->groups, cdf, n, stride, sizes, offsets);
+}
+
+int dcvc_rans_dec_empty_cdf(dcvc_rans_dec* d)
+{
+    DCVC_REQUIRE(d, "dcvc_rans_dec_empty_cdf: null coder");
+    d->worker[0].wait_idle();
+    d->worker[1].wait_idle();
+    d->groups.clear();
+    return 0;
 }
 
 void dcvc_rans_dec_set_use_two(dcvc_rans_dec* d, int two)

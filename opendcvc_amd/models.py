@@ -374,6 +374,7 @@ class CompressionModel(tnn.Module):
                                            H, W, C, self._stream()), "prior_finish")
 
     # one checkerboard decoding step = three pieces, so that the device pieces can sit inside captured runs
+    # (device index build -> host rANS decode -> device restore)
     def _index_to_host(self, groups, step, scales, H, W, C, key):
         """device: cdf indexes of the step's symbols -> pinned host buffer (stream-ordered copy)"""
         n = (C // groups) * H * W
@@ -392,14 +393,6 @@ class CompressionModel(tnn.Module):
         sym = torch.empty(n, dtype=torch.int8, device=yhat.device)
         check(_lib.lib().dcvc_memcpy_h2d(L._p(sym), ctypes.c_void_p(sym_host.ptr), n, self._stream()), "h2d")
         self._prior_dec_restore(groups, step, sym, means, yhat, H, W, C, out=out)
-
-    def _decode_step(self, groups, step, scales, means, yhat, H, W, C, key):
-        n = (C // groups) * H * W
-        hb = self._index_to_host(groups, step, scales, H, W, C, key)
-        ev = torch.cuda.Event()
-        ev.record()
-        ev.synchronize()
-        self._symbols_to_device(self._decode_on_host(hb, n, key), n, groups, step, means, yhat, H, W, C)
 
 
 # =============================================================================== DMC (P frames)
@@ -780,38 +773,47 @@ class DMCI(CompressionModel):
         return n["spatial_out"](L.dcb_chain([n["sp_adaptor"][step]] + n["spatial"], y_hat, common))
 
     def compress(self, x, qp):
-        """image_model.py:143-185 + compress_prior_4x (common_model.py:206-256)"""
+        """image_model.py:143-185 + compress_prior_4x (common_model.py:206-256).  Two captured runs, like DMC:
+        everything up to the symbol hand-off, then the synthesis transform (which overlaps the host entropy coder)."""
         dtype, device = self._ensure_layers()
         n = self._layers
         C = arch.DMCI_N
         x = x.to(device=device, dtype=dtype)
-        y = self._enc(x, self._q["q_scale_enc"][qp])
-        yh, yw = y.shape[0], y.shape[1]
-        z = n["hyper_enc"][2](n["hyper_enc"][1](n["hyper_enc"][0](self._pad_for_y(y))))
-        z_hat, z8 = self._quantize_z(z)
-        params = self._prior_params(z_hat, yh, yw)
-        common = n["reduction"](params)
-        scales, means = params[:, :, 2:2 + C], params[:, :, 2 + C:2 + 2 * C]
+        _, _, H, W = x.shape
+        xin = self._buffer("x_unshuffled", (H // 8, W // 8, 192), dtype, device)
+        self._unshuffle8(x, out=xin)
+        q = self._stage_q(qp)
+        key = (H, W)
 
-        nsym = (C // 4) * yh * yw
-        y_hat = torch.empty((yh, yw, C), dtype=dtype, device=device)
-        packed = torch.empty((4, nsym), dtype=torch.int16, device=device)
-        self._prior_enc_step(4, 0, 1, y, params, scales, means, y_hat, packed[0])
-        for step in (1, 2, 3):
-            sp = self._spatial_prior(y_hat, common, step)
-            self._prior_enc_step(4, step, 1, y, params, sp[:, :, :C], sp[:, :, C:], y_hat, packed[step])
-        self._prior_finish(1, y_hat, params)
+        def front():
+            y = n["enc_down"](L.dcb_chain(n["enc_2"], n["enc_1"](xin, quant=q["q_scale_enc"])))
+            yh, yw = y.shape[0], y.shape[1]
+            z = n["hyper_enc"][2](n["hyper_enc"][1](n["hyper_enc"][0](self._pad_for_y(y))))
+            z_hat, z8 = self._quantize_z(z)
+            params = self._prior_params(z_hat, yh, yw)
+            common = n["reduction"](params)
+            scales, means = params[:, :, 2:2 + C], params[:, :, 2 + C:2 + 2 * C]
+            nsym = (C // 4) * yh * yw
+            y_hat = torch.empty((yh, yw, C), dtype=dtype, device=device)
+            packed = torch.empty((4, nsym), dtype=torch.int16, device=device)
+            self._prior_enc_step(4, 0, 1, y, params, scales, means, y_hat, packed[0])
+            for step in (1, 2, 3):
+                sp = self._spatial_prior(y_hat, common, step)
+                self._prior_enc_step(4, step, 1, y, params, sp[:, :, :C], sp[:, :, C:], y_hat, packed[step])
+            self._prior_finish(1, y_hat, params)
+            return y_hat, self._d2h("z8", z8), self._d2h("packed", packed), z8.numel(), nsym, (z.shape[0], z.shape[1])
 
-        hz = self._d2h("z8", z8)
-        hp = self._d2h("packed", packed)
+        y_hat, hz, hp, nz, nsym, (zh, zw) = self._graphs.run(("ienc_front",) + key, front)
         ready = torch.cuda.Event()
         ready.record()
-        x_hat = self._dec(y_hat, self._q["q_scale_dec"][qp])
+        x_hat = self._graphs.run(("ienc_back",) + key, lambda: self._dec(y_hat, q["q_scale_dec"]))
+        if self._graphs.enabled:
+            x_hat = x_hat.clone()          # the captured run reuses its output buffer on the next frame
 
         ready.synchronize()
         ec = self.entropy_coder
         ec.reset()
-        ec.encode_z(hz.view(np.int8, z8.numel()), self._z_group, qp * self.z_channel, z.shape[0] * z.shape[1])
+        ec.encode_z(hz.view(np.int8, nz), self._z_group, qp * self.z_channel, zh * zw)
         ps = hp.view(np.int16, 4 * nsym)
         for k in range(4):
             ec.encode_y(ps[k * nsym:(k + 1) * nsym], self._g_group, borrowed=True)
@@ -820,7 +822,10 @@ class DMCI(CompressionModel):
         return {"bit_stream": bit_stream, "x_hat": x_hat}
 
     def decompress(self, bit_stream, sps, qp):
-        """image_model.py:187-209 + decompress_prior_4x (common_model.py:258-296)"""
+        """image_model.py:187-209 + decompress_prior_4x (common_model.py:258-296).  Five captured runs split at the
+        four host decoding steps (the reference's dependency structure: each checkerboard step needs the symbols of
+        the previous one); a run never updates an earlier run's output in place (GraphCache), so every step restores
+        into a fresh y_hat."""
         dtype, device = self._ensure_layers()
         n = self._layers
         C = arch.DMCI_N
@@ -830,17 +835,43 @@ class DMCI(CompressionModel):
         zh, zw = self.get_downsampled_shape(sps["height"], sps["width"], 64)
         yh, yw = self.get_downsampled_shape(sps["height"], sps["width"], 16)
         nz = self.z_channel * zh * zw
+        nsym = (C // 4) * yh * yw
+        key = (sps["height"], sps["width"])
+        q = self._stage_q(qp)
         ec.decode_z(nz, self._z_group, qp * self.z_channel, zh * zw)
         zb = ec.pinned("z_dec", nz)
         ec.get_decoded(zb.view(np.int8, nz))
-        z_hat = self._z_to_device(zb.view(np.int8, nz), zh, zw, dtype, device)
-        params = self._prior_params(z_hat, yh, yw)
-        common = n["reduction"](params)
-        y_hat = torch.empty((yh, yw, C), dtype=dtype, device=device)
-        self._decode_step(4, 0, params[:, :, 2:2 + C], params[:, :, 2 + C:2 + 2 * C], y_hat, yh, yw, C, "i0")
-        for step in (1, 2, 3):
-            sp = self._spatial_prior(y_hat, common, step)
-            self._decode_step(4, step, sp[:, :, :C], sp[:, :, C:], y_hat, yh, yw, C, f"i{step}")
-        self._prior_finish(1, y_hat, params)
-        x_hat = self._dec(y_hat, self._q["q_scale_dec"][qp])
+
+        def first():
+            z_hat = self._z_to_device(zb.view(np.int8, nz), zh, zw, dtype, device)
+            params = self._prior_params(z_hat, yh, yw)
+            common = n["reduction"](params)
+            return params, common, self._index_to_host(4, 0, params[:, :, 2:2 + C], yh, yw, C, "i0")
+
+        params, common, idx = self._graphs.run(("idec_0",) + key, first)
+        means = params[:, :, 2 + C:2 + 2 * C]
+        y_prev = None
+        for step in (0, 1, 2, 3):
+            ev = torch.cuda.Event()
+            ev.record()
+            ev.synchronize()                       # the index copy of this step has landed
+            sym = self._decode_on_host(idx, nsym, f"i{step}")
+
+            def after(step=step, sym=sym, means=means, y_prev=y_prev):
+                y_new = torch.empty((yh, yw, C), dtype=dtype, device=device)
+                self._symbols_to_device(sym, nsym, 4, step, means, y_new if y_prev is None else y_prev, yh, yw, C, out=y_new)
+                if step == 3:
+                    self._prior_finish(1, y_new, params)
+                    return y_new, self._dec(y_new, q["q_scale_dec"])
+                sp = self._spatial_prior(y_new, common, step + 1)
+                return y_new, sp, self._index_to_host(4, step + 1, sp[:, :, :C], yh, yw, C, f"i{step + 1}")
+
+            res = self._graphs.run((f"idec_{step + 1}",) + key, after)
+            if step == 3:
+                x_hat = res[1]
+            else:
+                y_prev, sp, idx = res
+                means = sp[:, :, C:]
+        if self._graphs.enabled:
+            x_hat = x_hat.clone()
         return {"x_hat": x_hat}

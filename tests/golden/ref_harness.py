@@ -21,13 +21,25 @@ def available():
     return os.path.isdir(os.path.join(REF_ROOT, "src", "models"))
 
 
-def load():
-    """Returns (DMC, DMCI, ref_layers_module, ref_cuda_inference_module, MLCodec_extensions_cpp)."""
+def load(coder="reference"):
+    """Returns (DMC, DMCI, ref_layers_module, ref_cuda_inference_module, MLCodec_extensions_cpp, stream_helper).
+
+    coder="reference": the reference's own rANS module compiled into oracle/_ref.
+    coder="shim": opendcvc_amd.mlcodec_shim registered as MLCodec_extensions_cpp - the REFERENCE's models then
+    entropy-code through the host coder of libdcvc_amd.so (drop-in seam 3, tests/test_mlcodec_shim.py)."""
     import torch
 
     os.environ.setdefault("SUPPRESS_CUSTOM_KERNEL_WARNING", "1")
     sys.dont_write_bytecode = True
-    for p in (REF_RANS_DIR, REF_ROOT):
+    if coder == "shim":
+        if REPO not in sys.path:
+            sys.path.insert(0, REPO)
+        from opendcvc_amd import mlcodec_shim
+        mlcodec_shim.install()
+    else:
+        sys.modules.pop("MLCodec_extensions_cpp", None) if getattr(
+            sys.modules.get("MLCodec_extensions_cpp"), "__name__", "") == "opendcvc_amd.mlcodec_shim" else None
+    for p in ((REF_ROOT,) if coder == "shim" else (REF_RANS_DIR, REF_ROOT)):
         if p not in sys.path:
             sys.path.insert(0, p)
 

@@ -8,9 +8,9 @@ dev = torch.device("cuda", 0)
 (ie, pe), (idec, pdec) = bench.load_models(torch.float16, dev, 1, 0)
 for m in (ie, idec):
     m.set_use_two_entropy_coders(True)
-frames = bench.make_frames(0, torch.float16, dev)[:4]
+frames = bench.make_frames(0, torch.float16, dev)[1][:6]
 sps = dict(height=1080, width=1920, ec_part=1, use_ada_i=0)
-for it in range(4):
+for it in range(6):
     x = frames[it]
     torch.cuda.synchronize(); t0 = time.perf_counter()
     enc = ie.compress(x, 32); torch.cuda.synchronize(); t1 = time.perf_counter()
