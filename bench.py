@@ -114,6 +114,28 @@ def roofline_leg(p_net, device, dtype):
             "head_kernel_ms": round(head.value, 4)}
 
 
+def window_start(steps):
+    """Frame index (mod GOP) at which the timed window starts: whole GOPs start on their I frame, a shorter window
+    gets the I frame in its middle."""
+    return (GOP - (steps % GOP) // 2) % GOP
+
+
+def measure(run, steps, warmup, world, device, sync):
+    """The timed region of the driver contract: `warmup` (+ the frames needed to place the window in the GOP) untimed
+    steps, barrier + device sync, EXACTLY `steps` steps, barrier + device sync, MAX over ranks.
+    run(n, timed) codes n frames; sync() waits for the device.  Returns (elapsed seconds, alignment frames)."""
+    align = (window_start(steps) - warmup) % GOP
+    sync()
+    run(warmup + align, False)
+    dist_utils.barrier(world)
+    sync()
+    t0 = time.perf_counter()
+    run(steps, True)
+    dist_utils.barrier(world)
+    sync()
+    return dist_utils.max_over_ranks(time.perf_counter() - t0, device, world), align
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -184,6 +206,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU: keep this rank's threads (2 pipeline threads + the rANS workers) on its share of the cores,
+    # those of its GPU's NUMA node when sysfs tells - before anything touches the GPU
+    cpus = dist_utils.pin_rank_threads(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else None
     _lib.require_gpu()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -228,23 +253,11 @@ def main():
 
         pipe.run((frames[k % GOP] for k in range(first, first + nsteps)), on_packet, on_frame)
 
-    def barrier():
-        dist_utils.barrier(world)
-        torch.cuda.synchronize()
-
     # Placement of the timed window in the GOP (the encoder codes an I frame whenever its frame counter is a multiple
     # of 32): whole GOPs start on an I frame; a shorter window gets one I frame in its middle - never a P-only window.
     K = args.steps
-    start = (GOP - (K % GOP) // 2) % GOP
-    align = (start - args.warmup) % GOP
-    torch.cuda.synchronize()
-    run_pipelined(args.warmup + align, False)
-    assert state["i"] % GOP == start
-    barrier()
-    t0 = time.perf_counter()
-    run_pipelined(K, True)
-    barrier()
-    elapsed = dist_utils.max_over_ranks(time.perf_counter() - t0, device, world)
+    elapsed, align = measure(run_pipelined, K, args.warmup, world, device, torch.cuda.synchronize)
+    assert state["i"] % GOP == (window_start(K) + K) % GOP
     assert state["j"] == args.warmup + align + K
     assert state["n_i"] >= max(1, K // GOP), "the timed window must contain I frames at the GOP's rate"
 
@@ -298,7 +311,7 @@ def main():
                                    "(BASELINE.json configs[%d])" % (("1080p", 1) if (WIDTH, HEIGHT) == (1920, 1080) else (args.frame, 3)),
                        "frame": "%dx%d padded to %dx%d" % (WIDTH, HEIGHT, WIDTH + (-WIDTH) % 16, HEIGHT + (-HEIGHT) % 16), "intra_period": GOP, "i_frames_timed": state["n_i"],
                        "i_frame_share_timed": round(state["n_i"] / float(K), 4), "i_frame_share_gop": round(1.0 / GOP, 4),
-                       "alignment_frames": align,
+                       "alignment_frames": align, "cpus_per_rank": len(cpus) if cpus else len(os.sched_getaffinity(0)),
                        "entropy_coders": 2 if two else 1, "force_zero_thres": THRES,
                        "weights": "synthetic seed 1234 (opendcvc_amd/weights.py)",
                        "pipeline": "encoder and decoder on two host threads / two HIP streams of the same GPU: frame n "

@@ -2,10 +2,70 @@
 collective - the reference does the same with a process pool, test_video.py:381-414,472-510).
 The only communication is a one-time broadcast of the weights from rank 0 (RCCL over xGMI when the
 backend is "nccl"; gloo on CPU in the tests) and the MAX reduction of the timed region."""
+import glob
+import os
+
 import numpy as np
 import torch
 
 from . import arch
+
+
+def _parse_cpulist(text):
+    out = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.update(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_local_cpus(sysfs="/sys/class/drm"):
+    """CPUs local to each AMD GPU (NUMA affinity of its PCI function), in PCI-address order - the order in which the
+    HIP runtime enumerates devices by default.  Read from sysfs: no GPU call is made.  [] if not available."""
+    gpus = []
+    for dev in glob.glob(os.path.join(sysfs, "renderD*", "device")):
+        try:
+            if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
+                continue
+            bdf = os.path.basename(os.path.realpath(dev))
+            gpus.append((bdf, _parse_cpulist(open(os.path.join(dev, "local_cpulist")).read())))
+        except (OSError, ValueError):
+            continue
+    return [c for _, c in sorted(gpus)]
+
+
+def rank_cpus(local_rank, local_world, allowed=None, gpu_cpus=None):
+    """The CPU set rank `local_rank` of `local_world` ranks on this node should run on: the allowed CPUs local to its
+    GPU's NUMA node, divided evenly between the ranks whose GPUs share that node; without topology information (or
+    when the local CPUs are not among the allowed ones) a contiguous 1/local_world slice of the allowed CPUs."""
+    allowed = sorted(os.sched_getaffinity(0) if allowed is None else allowed)
+    gpu_cpus = gpu_local_cpus() if gpu_cpus is None else gpu_cpus
+    if len(gpu_cpus) >= local_world and all(gpu_cpus[r] & set(allowed) for r in range(local_world)):
+        mine = sorted(gpu_cpus[local_rank] & set(allowed))
+        peers = [r for r in range(local_world) if gpu_cpus[r] == gpu_cpus[local_rank]]
+        k, n = peers.index(local_rank), len(peers)
+        part = mine[k * len(mine) // n:(k + 1) * len(mine) // n]
+        if part:
+            return part
+    n = len(allowed)
+    part = allowed[local_rank * n // local_world:(local_rank + 1) * n // local_world]
+    return part or allowed
+
+
+def pin_rank_threads(local_rank, local_world):
+    """Pins this process (every thread it starts later inherits the mask: the two pipeline threads, the rANS workers)
+    to rank_cpus(...).  SURVEY 8(e): with 8 ranks x (2 Python threads + up to 8 coder workers) the host cores are the
+    expected scaling limiter - without pinning the ranks' threads migrate across NUMA nodes.  Call before the first
+    GPU call.  Returns the CPU list (also when the mask could not be set)."""
+    cpus = rank_cpus(local_rank, local_world)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        pass
+    torch.set_num_threads(1)      # the reference does the same (src/utils/common.py:23): no intra-op pool per rank
+    return cpus
 
 
 def broadcast_state_dict(model_name, sd, device, rank, world):

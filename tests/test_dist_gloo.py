@@ -52,3 +52,65 @@ def test_single_rank_is_passthrough():
     sd = {"a": np.zeros(3, np.float32)}
     assert dist_utils.broadcast_state_dict("dmc", sd, torch.device("cpu"), 0, 1) is sd
     assert dist_utils.max_over_ranks(3.5, torch.device("cpu"), 1) == 3.5
+
+
+def _bench_worker(rank, world, port, q):
+    """bench.py's N > 1 control flow (measure(): warm-up + GOP alignment, barrier, timed region, barrier, MAX
+    reduce) on gloo / CPU with a stub in place of the codec: rank r takes (r + 1) ms per frame."""
+    import time
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cpus = dist_utils.pin_rank_threads(rank, world)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def run(n, timed):
+        calls.append((n, timed))
+        time.sleep(0.001 * (rank + 1) * n)
+
+    steps, warmup = 20, 5
+    t0 = time.perf_counter()
+    elapsed, align = bench.measure(run, steps, warmup, world, torch.device("cpu"), lambda: None)
+    wall = time.perf_counter() - t0
+    q.put((rank, elapsed, align, calls, sorted(cpus), wall))
+    dist.destroy_process_group()
+
+
+def test_bench_control_flow_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, e0, a0, c0, cpu0, _), (r1, e1, a1, c1, cpu1, _) = res
+    assert e0 == e1 and e0 >= 0.002 * 20 * 0.9                     # MAX over ranks: the slower rank's 2 ms per frame
+    assert a0 == a1 == (22 - 5) % 32                               # 20 timed frames start at frame 22: the I frame (32) is inside
+    assert c0 == c1 == [(5 + a0, False), (20, True)]              # exactly K timed steps after warm-up + alignment
+    assert cpu0 and cpu1 and not (set(cpu0) & set(cpu1))           # the two ranks were given disjoint cores
+
+
+def test_rank_cpu_partition():
+    allowed = list(range(64))
+    # no topology: contiguous slices
+    parts = [dist_utils.rank_cpus(r, 8, allowed, gpu_cpus=[]) for r in range(8)]
+    assert sorted(sum(parts, [])) == allowed and all(len(p) == 8 for p in parts)
+    # two NUMA nodes with four GPUs each: every rank stays on its GPU's node, ranks of a node split it
+    node = [set(range(0, 32))] * 4 + [set(range(32, 64))] * 4
+    parts = [dist_utils.rank_cpus(r, 8, allowed, gpu_cpus=node) for r in range(8)]
+    assert all(set(parts[r]) <= node[r] and len(parts[r]) == 8 for r in range(8))
+    assert sorted(sum(parts, [])) == allowed
+    # local CPUs outside the allowed set (container cpuset): fall back to slices of what is allowed
+    parts = [dist_utils.rank_cpus(r, 2, list(range(8)), gpu_cpus=[set(range(100, 110))] * 2) for r in range(2)]
+    assert parts == [[0, 1, 2, 3], [4, 5, 6, 7]]
+    assert dist_utils.rank_cpus(0, 1, allowed, gpu_cpus=[]) == allowed
