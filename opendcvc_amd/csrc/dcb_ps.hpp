@@ -38,9 +38,6 @@
 
 #include "gemm_core.hpp"
 
-#ifndef PS_DS
-#define PS_DS 6
-#endif
 namespace ps {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -82,8 +79,7 @@ struct Cfg {
     static constexpr int HEAD_SLOTS = NT;           // W1 tile-outer (one output tile per slot)
     // LDS: ring | halo slabs | tables
     static constexpr int RING_OFF = 0;
-    static constexpr int NBUF = 3;                  // LDS ring buffers (slot g lives in buffer g % 3)
-    static constexpr int DS = C <= 256 ? PS_DS : 2;     // slots in flight in registers between L2 and LDS
+    static constexpr int NBUF = 6;                  // LDS ring buffers (slot g lives in buffer g % 6), filled by LDS-DMA
     static constexpr int HALO_OFF = NBUF * SLOT_BYTES;
     static constexpr int TBL_OFF = HALO_OFF + 2 * SLAB_BYTES;
     // tables: wd [9][C] f16 | bd [C] f32 | b2 [C] | b3 [4C] | b4 [C] | nb1 [C]
@@ -137,6 +133,18 @@ __device__ __forceinline__ floatx16 mfma32(const half8& a, const half8& b, const
 
 __device__ __forceinline__ float gate1(float up) { return Traits<half_t>::gate(up); }
 
+// one LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to LDS bytes [lds_dst, lds_dst + 1024).
+// M0 carries the LDS address and is compiler-reserved: saved and restored inside the statement
+// (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
 // 8 consecutive fp32 values -> one B fragment (8 halves)
 __device__ __forceinline__ half8 pack8(const float (&v)[8])
 {
@@ -150,7 +158,7 @@ template <int C>
 __global__ __launch_bounds__(NTHR, 1) void dcb_tail_ps_kernel(Params p)
 {
     using CF = Cfg<C>;
-    constexpr int NT = CF::NT, KS = CF::KS, R = CF::R, SB = CF::SLOT_BYTES, DS = CF::DS, NBUF = CF::NBUF;
+    constexpr int NT = CF::NT, KS = CF::KS, R = CF::R, SB = CF::SLOT_BYTES, NBUF = CF::NBUF;
     constexpr int GS = NT / 2;                                 // fragments per read group: a slot = 4 groups
     static_assert(NT % 2 == 0, "fragment groups are half a k-step / a quarter of a u tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -169,51 +177,96 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_tail_ps_kernel(Params p)
     const char* tbl = smem + CF::TBL_OFF;
 
     // ---- weight ring -------------------------------------------------------------------------------------
-    // Slot g is requested from L2 at step g - 2 - DS, written to LDS buffer g % 3 at step g - 2 (after that step's
-    // barrier: every wave has left slot g - 3), published by the barrier of step g - 1 and consumed at step g, the
-    // fragment reads running one group (half a slot) ahead of the MFMAs.  Register set of slot g: g % DS - every
-    // call site knows g modulo DS and modulo 3 at compile time (the phases travel as integral_constants).
+    // LDS-DMA (global_load_lds_dwordx4: L2 -> LDS without passing through registers; measured on this chip, every CU
+    // streaming the same 896 KiB: 27 TB/s for bare DMA against ~10 TB/s through VGPRs, tools/dma_ring_mb.hip).
+    // Slot g is requested at step g - (NBUF - 1) into buffer g % NBUF, waited for (counted vmcnt: its requests are
+    // older than the NBUF - 3 slots issued after it) before the barrier of step g - 1 and consumed at step g, the
+    // fragment reads running one group ahead of the MFMAs across that barrier.  The DMA is issued from inline asm:
+    // hipcc then does not know that LDS is being written behind its back and leaves the ds_reads their counted
+    // lgkmcnt waits (with the builtin it drains vmcnt before every LDS read that may alias a transfer in flight).
     const int total_slots = CF::TAIL_SLOTS + (p.nstream ? CF::HEAD_SLOTS : 0);
-    Vec16 wq[DS][R];
-    auto slot_src = [&](int g) -> const Vec16* {
-        const int gc = g < total_slots ? g : total_slots - 1;      // (clamped: the loads past the end are harmless)
+    [[maybe_unused]] unsigned long long t_lds = 0, t_bar = 0, t_commit = 0;   // diagnostic build: where ring_step waits
+    const unsigned lds_base = (unsigned)(size_t)smem;         // LDS byte address of the dynamic segment
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto ring_issue = [&](auto buf, int g) {                  // slot g -> buffer B: R one-KiB pieces per wave
+        constexpr int B = decltype(buf)::value;
+        const int gc = g < total_slots ? g : total_slots - 1;      // (clamped: the requests past the end are harmless)
         const char* base = gc < CF::TAIL_SLOTS ? reinterpret_cast<const char*>(p.stream) + (size_t)gc * SB
                                                : reinterpret_cast<const char*>(p.nstream) + (size_t)(gc - CF::TAIL_SLOTS) * SB;
-        return reinterpret_cast<const Vec16*>(base) + tid;
-    };
-    auto ring_load = [&](auto set, int g) {
-        constexpr int S = decltype(set)::value;
-        const Vec16* s = slot_src(g);
 #pragma unroll
-        for (int k = 0; k < R; ++k) wq[S][k] = s[k * NTHR];
+        for (int k = 0; k < R; ++k) {
+            const int piece = wave_u * R + k;
+            glds16(base + piece * 1024 + lane * 16, lds_base + CF::RING_OFF + B * SB + piece * 1024);
+        }
     };
-    auto ring_commit = [&](auto set, auto buf) {
-        constexpr int S = decltype(set)::value, B = decltype(buf)::value;
-        Vec16* d = reinterpret_cast<Vec16*>(ring + B * SB) + tid;
+    // one piece of a slot (spread over the four MFMA groups of a step: a DMA takes ~50 issue cycles, four in a row
+    // drain the matrix pipe)
+    const char* issue_base = nullptr;
+    auto ring_issue_begin = [&](int g) {
+        const int gc = g < total_slots ? g : total_slots - 1;
+        issue_base = gc < CF::TAIL_SLOTS ? reinterpret_cast<const char*>(p.stream) + (size_t)gc * SB
+                                         : reinterpret_cast<const char*>(p.nstream) + (size_t)(gc - CF::TAIL_SLOTS) * SB;
+    };
+    auto ring_issue_piece = [&](auto buf, auto kc) {
+        constexpr int B = decltype(buf)::value, k0 = decltype(kc)::value;
 #pragma unroll
-        for (int k = 0; k < R; ++k) d[k * NTHR] = wq[S][k];
+        for (int k = k0; k < R; k += 4) {
+            const int piece = wave_u * R + k;
+            glds16(issue_base + piece * 1024 + lane * 16, lds_base + CF::RING_OFF + B * SB + piece * 1024);
+        }
     };
-    // step g (G = g as far as the phases are concerned): barrier, slot g+2 to LDS, slot g+2+DS requested
+    // step g (G = g as far as the phases are concerned): slot g + 1 landed, barrier, slot g + NBUF - 1 requested
     auto ring_step = [&](auto gph, int g) {
-        constexpr int G = decltype(gph)::value;
-        // Raw barrier instead of __syncthreads(): the fence of the latter waits for EVERY outstanding LDS operation,
-        // i.e. also for the fragment group requested a moment ago for the other side of the barrier.  What the
-        // barrier has to publish are the previous step's ds_writes (ring slot, halo slab): they are older than that
-        // group (LDS operations complete in order), so "at most NT still outstanding" covers them.
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(GS) : "memory");
+#ifdef DCVC_DIAG
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long ta = __builtin_amdgcn_s_memtime();
+#endif
+        // own requests of slot g + 1 have landed; own LDS reads of everything but the group requested a moment ago
+        // (the two groups for the other side of the barrier) have returned, in particular those of slot g - 1, whose buffer is
+        // overwritten after the barrier
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" ::"n"((NBUF - 3) * R), "n"(2 * GS) : "memory");
+#ifdef DCVC_DIAG
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long tb = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        ring_commit(ic<(G + 2) % DS>{}, ic<(G + 2) % NBUF>{});
-        ring_load(ic<(G + 2) % DS>{}, g + 2 + DS);
+#ifdef DCVC_DIAG
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long tc = __builtin_amdgcn_s_memtime();
+#endif
+        ring_issue_begin(g + NBUF - 1);           // (its pieces are issued by slot_groups, one per MFMA group)
+#ifdef DCVC_DIAG
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long td = __builtin_amdgcn_s_memtime();
+        t_lds += tb - ta;
+        t_bar += tc - tb;
+        t_commit += td - tc;
+#endif
     };
-    // fragment groups: GS fragments (a quarter of a slot) at a time, double buffered and read one group ahead of the
-    // MFMAs (across the slot boundary too): FA = groups 0 and 2 of a slot, FB = groups 1 and 3
-    half8 FA[GS], FB[GS];
-    auto read_group = [&](half8 (&F)[GS], auto gph, int grp) {
-        constexpr int B = decltype(gph)::value % NBUF;
+    // fragment groups: GS fragments (a quarter of a slot) at a time in a three-deep register ring, read TWO groups
+    // (2 GS MFMAs = 256 cycles at C = 256) ahead of the MFMAs that use them, across the slot boundary too: with four
+    // waves reading 1 KiB per MFMA and the DMA writing next to them an LDS read takes a few hundred cycles to return.
+    // Global group index Q = 4 * slot + (0..3); buffer Q % 3.
+    half8 F0[GS], F1[GS], F2[GS];
+    auto read_q = [&](auto qc) {
+        constexpr int Q = decltype(qc)::value, B = (Q / 4) % NBUF, grp = Q % 4;
         const char* src = ring + B * SB + grp * GS * 1024 + lane * 16;
 #pragma unroll
-        for (int t = 0; t < GS; ++t) F[t] = *reinterpret_cast<const half8*>(src + t * 1024);
+        for (int t = 0; t < GS; ++t) {
+            const half8 v = *reinterpret_cast<const half8*>(src + t * 1024);
+            if constexpr (Q % 3 == 0) F0[t] = v; else if constexpr (Q % 3 == 1) F1[t] = v; else F2[t] = v;
+        }
+    };
+    // the four groups of slot G: request group Q + 2, then body(j, fragments of group Q)
+    auto slot_groups = [&](auto gph, auto&& body) {
+        constexpr int G = decltype(gph)::value;
+        static_for<4>([&](auto jc) {
+            constexpr int Q = 4 * G + decltype(jc)::value;
+            ring_issue_piece(ic<(G + NBUF - 1) % NBUF>{}, jc);
+            read_q(ic<Q + 2>{});
+            if constexpr (Q % 3 == 0) body(jc, F0); else if constexpr (Q % 3 == 1) body(jc, F1); else body(jc, F2);
+        });
     };
 
     // ---- halo slabs ------------------------------------------------------------------------------------------
@@ -245,8 +298,8 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_tail_ps_kernel(Params p)
 
     PS_STAMP(0);
     // ---- prologue ------------------------------------------------------------------------------------------
-    // slots 0 and 1 go to LDS before the first barrier, slots 2 .. 1 + DS wait in registers
-    ring_load(ic<0>{}, 0);
+    // the first NBUF - 1 ring slots are requested right away; halo slab 0 and the tables follow through registers
+    static_for<NBUF - 1>([&](auto d) { ring_issue(d, decltype(d)::value); });
     halo_load(0);
     {   // tables -> LDS (plain copy, 16-byte pieces)
         const Vec16* src = reinterpret_cast<const Vec16*>(p.tables);
@@ -258,12 +311,8 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_tail_ps_kernel(Params p)
             for (int it = tid; it < C * 4 / 16; it += NTHR) nd[it] = nb[it];
         }
     }
-    ring_commit(ic<0>{}, ic<0>{});
-    ring_load(ic<0>{}, 1);
     halo_commit(0);
     halo_load(1);
-    ring_commit(ic<0>{}, ic<1>{});
-    static_for<DS>([&](auto d) { ring_load(ic<(2 + decltype(d)::value) % DS>{}, 2 + decltype(d)::value); });
     Vec16 idf[KS];      // identity fragments of this lane's pixel: idf[ks] = x'[pixel][16 ks + 8 h .. +7] (requested below)
 
     // depthwise of k-step ks for this lane's pixel: 8 channels x 9 taps -> B fragment
@@ -311,16 +360,17 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_tail_ps_kernel(Params p)
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 3) * R) : "memory");     // slots 0 and 1 have landed
     __syncthreads();                                           // slots 0 and 1, slab 0, tables visible
     PS_STAMP(1);
     halo_commit(1);
-    read_group(FA, ic<0>{}, 0);
+    read_q(ic<0>{});
+    read_q(ic<1>{});
     half8 d_cur = dw(0);
-    static_for<NT>([&](auto ii) {                              // slot i: k-steps 2 i (group A), 2 i + 1 (group B)
+    static_for<NT>([&](auto ii) {                              // slot i: k-step 2 i (groups 0, 1), 2 i + 1 (groups 2, 3)
         constexpr int i = decltype(ii)::value;
         if constexpr (i == 0) {                                // (the barrier above was step 0's)
-            ring_commit(ic<2 % DS>{}, ic<2 % NBUF>{});
-            ring_load(ic<2 % DS>{}, 2 + DS);
+            ring_issue_begin(NBUF - 1);
         } else {
             ring_step(ii, i);
             // slab s+1 is written at slot 2 s (it is first read one k-step before slot 2 s + 2) and requested at 2 s - 1
@@ -334,26 +384,18 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_tail_ps_kernel(Params p)
                 if (pvalid) idf[ks] = *reinterpret_cast<const Vec16*>(ident + gpix * p.ldi + ks * 16 + h * 8);
             }
         }
-        {
-            read_group(FB, ii, 1);
-            const half8 d_next = dw(2 * i + 1);
+        const half8 d_n1 = dw(2 * i + 1);
+        half8 d_n2 = d_n1;
+        slot_groups(ii, [&](auto jc, const half8 (&F)[GS]) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j == 2) {
+                d_cur = d_n1;
+                d_n2 = dw(2 * i + 2 < KS ? 2 * i + 2 : KS - 1);
+            }
 #pragma unroll
-            for (int t = 0; t < GS; ++t) acc[t] = mfma32(FA[t], d_cur, acc[t]);
-            read_group(FA, ii, 2);
-#pragma unroll
-            for (int t = 0; t < GS; ++t) acc[GS + t] = mfma32(FB[t], d_cur, acc[GS + t]);
-            d_cur = d_next;
-        }
-        {
-            read_group(FB, ii, 3);
-            const half8 d_next = dw(2 * i + 2 < KS ? 2 * i + 2 : KS - 1);
-#pragma unroll
-            for (int t = 0; t < GS; ++t) acc[t] = mfma32(FA[t], d_cur, acc[t]);
-            read_group(FA, ic<i + 1>{}, 0);                    // next slot's first group (published by this step's barrier)
-#pragma unroll
-            for (int t = 0; t < GS; ++t) acc[GS + t] = mfma32(FB[t], d_cur, acc[GS + t]);
-            d_cur = d_next;
-        }
+            for (int t = 0; t < GS; ++t) acc[(j & 1) * GS + t] = mfma32(F[t], d_cur, acc[(j & 1) * GS + t]);
+        });
+        d_cur = d_n2;
     });
 
     PS_STAMP(2);
@@ -380,38 +422,22 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_tail_ps_kernel(Params p)
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     // one 32-row u tile = one slot: FA holds its k-steps 0..NT-1 on entry, FB gets NT..KS-1, FA the next slot's first half
     auto u_slot = [&](auto gph, int g, floatx16& u, int bias_off) {
-        constexpr int G = decltype(gph)::value;
         ring_step(gph, g);
         u = bias16(CF::T_B3, bias_off);
-        read_group(FB, gph, 1);
+        slot_groups(gph, [&](auto jc, const half8 (&F)[GS]) {
+            constexpr int j = decltype(jc)::value;
 #pragma unroll
-        for (int k = 0; k < GS; ++k) u = mfma32(FA[k], o[k], u);
-        read_group(FA, gph, 2);
-#pragma unroll
-        for (int k = 0; k < GS; ++k) u = mfma32(FB[k], o[GS + k], u);
-        read_group(FB, gph, 3);
-#pragma unroll
-        for (int k = 0; k < GS; ++k) u = mfma32(FA[k], o[2 * GS + k], u);
-        read_group(FA, ic<G + 1>{}, 0);
-#pragma unroll
-        for (int k = 0; k < GS; ++k) u = mfma32(FB[k], o[3 * GS + k], u);
+            for (int k = 0; k < GS; ++k) u = mfma32(F[k], o[j * GS + k], u);
+        });
     };
     // one W4 slot: v tile's two k-steps into the C/32 output tiles
     auto w4_slot = [&](auto gph, int g, const half8 (&vf)[2]) {
-        constexpr int G = decltype(gph)::value;
         ring_step(gph, g);
-        read_group(FB, gph, 1);
+        slot_groups(gph, [&](auto jc, const half8 (&F)[GS]) {
+            constexpr int j = decltype(jc)::value;
 #pragma unroll
-        for (int t = 0; t < GS; ++t) acc[t] = mfma32(FA[t], vf[0], acc[t]);
-        read_group(FA, gph, 2);
-#pragma unroll
-        for (int t = 0; t < GS; ++t) acc[GS + t] = mfma32(FB[t], vf[0], acc[GS + t]);
-        read_group(FB, gph, 3);
-#pragma unroll
-        for (int t = 0; t < GS; ++t) acc[t] = mfma32(FA[t], vf[1], acc[t]);
-        read_group(FA, ic<G + 1>{}, 0);
-#pragma unroll
-        for (int t = 0; t < GS; ++t) acc[GS + t] = mfma32(FB[t], vf[1], acc[GS + t]);
+            for (int t = 0; t < GS; ++t) acc[(j & 1) * GS + t] = mfma32(F[t], vf[j >> 1], acc[(j & 1) * GS + t]);
+        });
     };
     // step j: [tile j+1's u_lo slot | first half of tile j's gate] [u_hi slot | second half] [tile j's W4 slot]
     // G = phase of the step's first slot; g = its real index
@@ -437,12 +463,12 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_tail_ps_kernel(Params p)
         w4_slot(ic<G + (more ? 2 : 0)>{}, g + (more ? 2 : 0), vf);
     };
     PS_STAMP(3);
-    constexpr int G0 = NT;                                     // phase bookkeeping: phases only matter mod lcm(DS, 3)
+    constexpr int G0 = NT;                                     // phase bookkeeping: phases only matter mod NBUF
     floatx16 ua_lo, ua_hi, ub_lo, ub_hi;                       // two named tile pairs (no register-array indexing)
     u_slot(ic<G0>{}, G0, ua_lo, 0);
     u_slot(ic<G0 + 1>{}, G0 + 1, ua_hi, 2 * C);
     constexpr int GF = G0 + 2;                                 // first slot of step 0
-    static_assert(12 % DS == 0 && KS % 4 == 0, "the FFN loop advances 4 steps = 12 slots per iteration");
+    static_assert(12 % NBUF == 0 && KS % 4 == 0, "the FFN loop advances 4 steps = 12 slots per iteration");
     int g = GF;
     for (int j = 0; j + 4 < KS; j += 4, g += 12) {
         ffn_step(ic<GF + 0>{}, ic<1>{}, g + 0, j + 0, ua_lo, ua_hi, ub_lo, ub_hi);
@@ -533,18 +559,11 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_tail_ps_kernel(Params p)
                 constexpr int G = GH + t;
                 ring_step(ic<G>{}, g + t);
                 u = bias16(CF::T_NB1, 32 * t);
-                read_group(FB, ic<G>{}, 1);
+                slot_groups(ic<G>{}, [&](auto jc, const half8 (&F)[GS]) {
+                    constexpr int j = decltype(jc)::value;
 #pragma unroll
-                for (int k = 0; k < GS; ++k) u = mfma32(FA[k], r[k], u);
-                read_group(FA, ic<G>{}, 2);
-#pragma unroll
-                for (int k = 0; k < GS; ++k) u = mfma32(FB[k], r[GS + k], u);
-                read_group(FB, ic<G>{}, 3);
-#pragma unroll
-                for (int k = 0; k < GS; ++k) u = mfma32(FA[k], r[2 * GS + k], u);
-                read_group(FA, ic<G + 1>{}, 0);
-#pragma unroll
-                for (int k = 0; k < GS; ++k) u = mfma32(FB[k], r[3 * GS + k], u);
+                    for (int k = 0; k < GS; ++k) u = mfma32(F[k], r[j * GS + k], u);
+                });
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -558,6 +577,14 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_tail_ps_kernel(Params p)
         store_tile(an, reinterpret_cast<half_t*>(p.na_out), p.nlda, false);
     }
     PS_STAMP(7);
+#ifdef DCVC_DIAG
+    if (p.stamps && (threadIdx.x & 63) == 0) {      // per wave: cycles waited in ring_step (LDS drain | barrier | commit)
+        unsigned long long* w = p.stamps + (size_t)gridDim.x * 8 + ((size_t)blockIdx.x * 4 + wave) * 3;
+        w[0] = t_lds;
+        w[1] = t_bar;
+        w[2] = t_commit;
+    }
+#endif
 }
 
 }  // namespace ps

@@ -865,10 +865,10 @@ int launch_tail_ps(const ps::Params& pp, int H, int W, hipStream_t st)
     static const bool want_stamps = getenv("DCVC_STAMPS") != nullptr;
     if (want_stamps) {   // developer build only: median cycles per phase over the workgroups
         ps::Params q = pp;
-        DCVC_HIP(hipMalloc(&q.stamps, (size_t)grid * 8 * sizeof(unsigned long long)));
+        DCVC_HIP(hipMalloc(&q.stamps, (size_t)grid * 20 * sizeof(unsigned long long)));
         hipLaunchKernelGGL((ps::dcb_tail_ps_kernel<C>), dim3(grid), dim3(ps::NTHR), lds, st, q);
         DCVC_HIP(hipStreamSynchronize(st));
-        std::vector<unsigned long long> hs((size_t)grid * 8);
+        std::vector<unsigned long long> hs((size_t)grid * 20);
         DCVC_HIP(hipMemcpy(hs.data(), q.stamps, hs.size() * 8, hipMemcpyDeviceToHost));
         (void)hipFree(q.stamps);
         static int printed = 0;
@@ -891,8 +891,16 @@ int launch_tail_ps(const ps::Params& pp, int H, int W, hipStream_t st)
             for (int b = 0; b < grid; ++b) st0[b] = hs[(size_t)b * 8] - t0;
             std::sort(st0.begin(), st0.end());
             std::sort(tot.begin(), tot.end());
-            fprintf(stderr, " | total med %llu max %llu span %llu start med %llu max %llu\n", tot[grid / 2], tot[grid - 1],
-                    t1 - t0, st0[grid / 2], st0[grid - 1]);
+            fprintf(stderr, " | total med %llu max %llu\n", tot[grid / 2], tot[grid - 1]);
+            const char* wn[3] = {"lds_drain", "barrier", "commit(vmcnt)"};
+            fprintf(stderr, "   ring_step waits per wave (median over waves):");
+            for (int k = 0; k < 3; ++k) {
+                std::vector<unsigned long long> v((size_t)grid * 4);
+                for (size_t w = 0; w < v.size(); ++w) v[w] = hs[(size_t)grid * 8 + w * 3 + k];
+                std::sort(v.begin(), v.end());
+                fprintf(stderr, " %s=%llu", wn[k], v[v.size() / 2]);
+            }
+            fprintf(stderr, "\n");
         }
         return 0;
     }
