@@ -146,6 +146,20 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cores():
+    """CPUs this process may really use: the affinity mask, cut down to the cgroup CPU quota if there is one (a GPU box
+    shows all 256 hardware threads of the host but grants a 16-CPU share) and to 32 (the oracle's OpenMP loops are
+    not tuned beyond that)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / float(period)))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
 def cpu_baseline_leg():
     """The oracle (CPU port of the reference path, fp32) on P frames of a 480x272 crop: warm-up (2 frames; 1 in the
     single-thread leg) + 3 timed frames (encode + decode each) at 1 thread and at all cores, frames/s
@@ -157,7 +171,7 @@ def cpu_baseline_leg():
         gomp = ctypes.CDLL("libgomp.so.1")
     except OSError:
         gomp = None
-    ncores = len(os.sched_getaffinity(0))
+    ncores = usable_cores()
     h, w = 272, 480
     scale = (h * w) / float((HEIGHT + (-HEIGHT) % 16) * (WIDTH + (-WIDTH) % 16))
     frames = [weights.synthetic_frame_yuv444(h, w, fi, 0) for fi in range(6)]

