@@ -281,27 +281,37 @@ def main():
     run_pipelined((-state["i"]) % GOP, False)
     assert state["i"] % GOP == 0
     n_seq = GOP
-    pending = []                                    # the decoder emits P pictures one call late
+    # encoder pass, then decoder pass (the reference codes a whole sequence before it decodes it, test_video.py:172-298).
+    # Both run with their deferred forms: a P frame's entropy coding / reconstruction network is finished underneath
+    # the next frame's kernels, so packets and pictures come out one call late; every frame is complete at the end.
+    enc.defer = True
+    pkts, pending = [], []
     t_seq0 = time.perf_counter()
     for k in range(n_seq):
-        x = frames[k]
         state["i"] += 1
         ta = time.perf_counter()
         with torch.cuda.stream(s_enc):
-            pkt = enc.encode(x)
+            pkts += enc.encode(frames[k])
         torch.cuda.synchronize()
+        state["t_enc"] += time.perf_counter() - ta
+    ta = time.perf_counter()
+    pkts += enc.flush()
+    state["t_enc"] += time.perf_counter() - ta
+    enc.defer = False
+    for pkt in pkts:
         tb = time.perf_counter()
         with torch.cuda.stream(s_dec):
             pending += dec.decode(pkt)
         torch.cuda.synchronize()
-        tc = time.perf_counter()
-        state["t_enc"] += tb - ta
-        state["t_dec"] += tc - tb
+        state["t_dec"] += time.perf_counter() - tb
         state["seq_bytes"] += len(pkt.bit_stream)
+    tb = time.perf_counter()
     with torch.cuda.stream(s_dec):
         pending += dec.flush()
     torch.cuda.synchronize()
+    state["t_dec"] += time.perf_counter() - tb
     t_seq = time.perf_counter() - t_seq0
+    assert len(pkts) == n_seq
     assert len(pending) == n_seq
     for k, x_hat in enumerate(pending):             # (not timed) the reference's per-plane PSNR on the 8-bit planes
         state["psnr"].append(yuv420_distortion(x_hat, *planes[k]))
@@ -333,7 +343,9 @@ def main():
                                    "decoder emits P pictures one call late (their reconstruction network fills the next "
                                    "frame's host-decoding gaps)",
                        "baseline_note": "vs_baseline = sequential_fps_per_gpu / (1/(1/125.2+1/112.8)) fps (reference README, "
-                                        "A100 fp16, encode and decode timed one after the other as in the reference)"},
+                                        "A100 fp16, encode and decode timed one after the other as in the reference); the "
+                                        "sequential pass is one whole GOP, encoder loop then decoder loop, each frame "
+                                        "synchronised, P-frame streams / pictures completed one call late"},
             "sequential_fps_per_gpu": round(seq_value, 3), "sequential_ms_per_step": round(1e3 * t_seq / n_seq, 3),
             "enc_fps_per_gpu": round(n_seq / state["t_enc"], 2), "dec_fps_per_gpu": round(n_seq / state["t_dec"], 2),
             "bpp": round(state["bytes"] * 8.0 / (K * HEIGHT * WIDTH), 5),

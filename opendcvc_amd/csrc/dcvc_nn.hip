@@ -1054,7 +1054,8 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         // Widths of 384 and up (6+ channel tiles per wave) fit one workgroup per CU only.  Eight waves
         // (two per SIMD, half the channel tiles each, <= 256 VGPRs) give every SIMD a second wave of the
         // same tile to switch to: 144 -> 117 us at C=384, 136x240.  At C <= 256 two independent 4-wave
-        // workgroups per CU do that job better (8 waves there measured 116 us vs 63 us).
+        // workgroups per CU do that job better (8 waves there measured 116 us vs 63 us; 128-pixel tiles on 8 waves,
+        // MT = 8 x NTW = 2, spill at 256 VGPRs and measured 66 us against 59 us for the same build).
         int rc;
         if constexpr (NTW >= 6 && NTW % 2 == 0 && sizeof(T) == 2)
             rc = launch_tail<T, MT, NTW / 2, 8>(tp, grid, C, st);

@@ -408,6 +408,8 @@ class DMC(CompressionModel):
         self.curr_poc = 0
         self._ahead = None       # (height, width, x1, ctx): feature extractor of the NEXT frame, run ahead
         self._pending = None     # decoder, deferred output: the reconstruction network of the previous frame still to run
+        self._stream_pending = None   # encoder, deferred stream: symbols of the previous frame still to be entropy coded
+        self._stream_parity = 0
 
     def _build_layers(self, sd, dt):
         D, C2, R = L.DepthConvBlock, L.Conv2d, L.ResidualBlockWithStride2
@@ -566,10 +568,34 @@ class DMC(CompressionModel):
             return n["fa_i"](self._unshuffle8(ref_buf))
         return n["fa_p"](ref_buf)
 
-    def compress(self, x, qp):
+    def _code_symbols(self, job):
+        """host: entropy-codes one frame's symbols (waits for their copy to the pinned staging first)"""
+        ready, hz, hp, nz, nsym, zhw, qp = job
+        ready.synchronize()
+        ec = self.entropy_coder
+        ec.reset()
+        ec.encode_z(hz.view(np.int8, nz), self._z_group, qp * self.z_channel, zhw)
+        ps = hp.view(np.int16, 2 * nsym)
+        ec.encode_y(ps[:nsym], self._g_group, borrowed=True)     # pinned staging buffer, untouched until
+        ec.encode_y(ps[nsym:], self._g_group, borrowed=True)     # get_encoded_stream() below
+        ec.flush()
+        return ec.get_encoded_stream()
+
+    def finish_stream(self):
+        """Deferred encoder stream: entropy-codes and returns the bit stream of the last compress(..., defer_stream=True)
+        (None if there is none).  Called implicitly by the next compress."""
+        job, self._stream_pending = self._stream_pending, None
+        return None if job is None else self._code_symbols(job)
+
+    def compress(self, x, qp, defer_stream=False):
         """video_model.py:299-341.  x: [1,3,H,W] in [0,1], H and W multiples of 16.
         Two captured runs: everything up to the symbol hand-off, then the decoder (which overlaps the host
-        entropy coding)."""
+        entropy coding).
+
+        defer_stream=True (not in the reference API; the encoder-side mirror of decompress(defer_output=True)): the
+        symbols of THIS frame are entropy coded during the next call, underneath that frame's kernels - the returned
+        dict then carries the PREVIOUS frame's stream under 'bit_stream_prev' and 'bit_stream' is None;
+        finish_stream() returns the last one.  Same symbols, same bytes; a sequential encoder becomes GPU-bound."""
         dtype, device = self._ensure_layers()
         n = self._layers
         C = arch.DMC_CH_Y
@@ -606,12 +632,16 @@ class DMC(CompressionModel):
             sp = self._spatial_prior(y_hat, params)
             self._prior_enc_step(2, 1, 0, y, params[:, :, :C], sp[:, :, :C], sp[:, :, C:], y_hat, packed[1])
             self._prior_finish(0, y_hat, params[:, :, :C])
-            hz = self._d2h("z8", z8)
-            hp = self._d2h("packed", packed)
-            return y_hat, ctx, hz, hp, z8.numel(), nsym, (z.shape[0], z.shape[1])
+            return y_hat, ctx, z8, packed, z8.numel(), nsym, (z.shape[0], z.shape[1])
 
-        y_hat, ctx, hz, hp, nz, nsym, (zh, zw) = self._graphs.run(
+        y_hat, ctx, z8, packed, nz, nsym, (zh, zw) = self._graphs.run(
             ("enc_front_ahead" if ahead is not None else "enc_front",) + key, front)
+        # symbols -> pinned staging (outside the captured run: two staging sets alternate, so that the host may still
+        # be coding the previous frame out of the other one while this copy lands)
+        par = self._stream_parity
+        self._stream_parity ^= 1
+        hz = self._d2h(f"z8_{par}", z8)
+        hp = self._d2h(f"packed_{par}", packed)
         ready = torch.cuda.Event()
         ready.record()
         # the decoder keeps the GPU busy while the host codes
@@ -625,20 +655,18 @@ class DMC(CompressionModel):
                 return x1n, self._extractor_part2(x1n)
             nxt = (H, W) + tuple(self._graphs.run(("enc_ahead", H, W), extractor_ahead))
 
-        ready.synchronize()
-        ec = self.entropy_coder
-        ec.reset()
-        ec.encode_z(hz.view(np.int8, nz), self._z_group, qp * self.z_channel, zh * zw)
-        ps = hp.view(np.int16, 2 * nsym)
-        ec.encode_y(ps[:nsym], self._g_group, borrowed=True)     # pinned staging buffer, untouched until
-        ec.encode_y(ps[nsym:], self._g_group, borrowed=True)     # get_encoded_stream() below
-        ec.flush()
-        bit_stream = ec.get_encoded_stream()
+        # host entropy coding: the previous frame's deferred symbols first (its staging set is reused two frames on)
+        prev = self.finish_stream()
+        job = (ready, hz, hp, nz, nsym, zh * zw, qp)
         # no device synchronisation here (the reference has none either): the tail of the decoder stays in
         # flight on this stream and overlaps the caller's next host work; callers that time a frame sync.
         self.add_ref_frame(fbuf, None)
         self._ahead = nxt
-        return {"bit_stream": bit_stream}
+        if defer_stream:
+            self._stream_pending = job
+            return {"bit_stream": None, "bit_stream_prev": prev}
+        bit_stream = self._code_symbols(job)
+        return {"bit_stream": bit_stream} if prev is None else {"bit_stream": bit_stream, "bit_stream_prev": prev}
 
     def decompress(self, bit_stream, sps, qp, defer_output=False):
         """video_model.py:343-376.  Five captured runs, separated by the three host decoding steps

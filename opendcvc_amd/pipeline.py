@@ -17,8 +17,15 @@ class FramePacket:
 
 
 class SequenceEncoder:
-    def __init__(self, i_net, p_net, qp_i, qp_p=None, intra_period=-1, reset_interval=32):
+    """defer_stream=False: encode(x) returns the frame's packet (the reference's loop).
+    defer_stream=True: P-frame packets come out one call late - encode(x) returns a LIST of the packets completed by
+    the call, in order, flush() the rest; the host entropy coding of a P frame then runs underneath the next frame's
+    kernels (DMC.compress(defer_stream=True)), which makes a sequential encoder GPU-bound."""
+
+    def __init__(self, i_net, p_net, qp_i, qp_p=None, intra_period=-1, reset_interval=32, defer_stream=False):
         self.i_net, self.p_net = i_net, p_net
+        self.defer = defer_stream
+        self._held = None            # (qp, use_ada_i) of the P frame whose stream is still pending
         self.qp_i = qp_i
         self.qp_p = qp_i if qp_p is None else qp_p
         self.intra_period = intra_period
@@ -32,22 +39,41 @@ class SequenceEncoder:
         with CAPTURE_GUARD.frame():          # (a HIP graph capture on another thread waits for / holds back this frame)
             return self._encode(x_padded)
 
+    def _take_held(self, stream):
+        out = []
+        if self._held is not None and stream is not None:
+            out.append(FramePacket(False, self._held[0], self._held[1], stream))
+            self._held = None
+        return out
+
     def _encode(self, x_padded):
         fi = self.frame_idx
         self.frame_idx += 1
         if fi == 0 or (self.intra_period > 0 and fi % self.intra_period == 0):
+            done = self._take_held(self.p_net.finish_stream()) if self.defer else []
             enc = self.i_net.compress(x_padded, self.qp_i)
             self.p_net.clear_dpb()
             self.p_net.add_ref_frame(None, enc["x_hat"])
-            return FramePacket(True, self.qp_i, 0, enc["bit_stream"])
+            pkt = FramePacket(True, self.qp_i, 0, enc["bit_stream"])
+            return done + [pkt] if self.defer else pkt
         use_ada_i = 0
         if self.reset_interval > 0 and fi % self.reset_interval == 1:
             use_ada_i = 1
             self.p_net.prepare_feature_adaptor_i(self.last_qp)
         qp = self.p_net.shift_qp(self.qp_p, INDEX_MAP[fi % 8])
-        enc = self.p_net.compress(x_padded, qp)
+        enc = self.p_net.compress(x_padded, qp, defer_stream=self.defer)
         self.last_qp = qp
-        return FramePacket(False, qp, use_ada_i, enc["bit_stream"])
+        if not self.defer:
+            return FramePacket(False, qp, use_ada_i, enc["bit_stream"])
+        done = self._take_held(enc.get("bit_stream_prev"))
+        self._held = (qp, use_ada_i)
+        return done
+
+    def flush(self):
+        """defer_stream: the packet still pending (empty list otherwise)"""
+        from .models import CAPTURE_GUARD
+        with CAPTURE_GUARD.frame():
+            return self._take_held(self.p_net.finish_stream()) if self.defer else []
 
 
 class SequenceDecoder:

@@ -300,3 +300,28 @@ def test_update_twice_keeps_working():
         m.update(0.12)
     again = _encode_decode(e, d, 64, 96, 3, dtype)
     assert [b for b, _ in again] == [b for b, _ in first] and all(np.array_equal(a[1], b[1]) for a, b in zip(again, first))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_deferred_encoder_stream_equals_immediate(dtype):
+    """SequenceEncoder(defer_stream=True): a P frame's symbols are entropy coded during the next call and its packet
+    comes out one call late - same packets, same order, across I frames (intra period 4) and feature refreshes."""
+    from opendcvc_amd.pipeline import SequenceEncoder
+    h, w, n = 96, 160, 10
+    frames = [torch.from_numpy(weights.synthetic_frame_yuv444(h, w, fi, 7)).to("cuda", dtype) for fi in range(n)]
+    outs = []
+    for defer in (False, True):
+        ie, pe = hip_codecs(1234, 0.12, dtype)
+        for m in (ie, pe):
+            m.set_use_two_entropy_coders(False)
+        enc = SequenceEncoder(ie, pe, 28, intra_period=4, reset_interval=3, defer_stream=defer)
+        got = []
+        for x in frames:
+            r = enc.encode(x)
+            got += r if defer else [r]
+        got += enc.flush()
+        outs.append(got)
+    assert len(outs[0]) == len(outs[1]) == n
+    for fi, (a, b) in enumerate(zip(*outs)):
+        assert (a.is_i, a.qp, a.use_ada_i) == (b.is_i, b.qp, b.use_ada_i), fi
+        assert a.bit_stream == b.bit_stream, f"frame {fi}: deferred stream differs"
