@@ -1,11 +1,6 @@
 set -o pipefail
-mkdir -p gpurun_out/prof
-cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-cat /sys/fs/cgroup/cpu.max 2>/dev/null; nproc
-python -m pytest tests/test_harness.py -m gpu -x -q 2>&1 | tail -3
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -x -q > gpurun_out/r2_tests6.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r2_tests6.log
 python bench.py --steps 20 --warmup 5 > gpurun_out/r2_bench_20.json 2> gpurun_out/r2_bench_20.err; echo "bench20 rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/bench -o bench -- python bench.py --steps 64 --warmup 8 --no-cpu-baseline > gpurun_out/r2_bench_under_rocprof.json 2> gpurun_out/prof/bench.err; echo "rocprof bench rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/roof -o roof -- python bench.py --roofline-only > gpurun_out/r2_roofline_under_rocprof.json 2> gpurun_out/prof/roof.err; echo "rocprof roof rc=$?"
-find gpurun_out/prof -name "*kernel_stats.csv" | head
-rm -f gpurun_out/prof/*/*.db gpurun_out/prof/*/*kernel_trace.csv
-python tools/iframe_time.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r2_iframe_time.txt; tail -2 gpurun_out/r2_iframe_time.txt
+python bench.py > gpurun_out/r2_bench_default.json 2> gpurun_out/r2_bench_default.err; echo "bench rc=$?"
+python tools/make_yuv.py 1920 1080 12 0 /tmp/seq1080.yuv && python -m opendcvc_amd.harness --src /tmp/seq1080.yuv --width 1920 --height 1080 --frames 12 --rate-num 4 --intra-period -1 --reset-interval 8 --verbose-json --out gpurun_out/r2_sweep_1080p_fp16.json 2> gpurun_out/r2_sweep.err; echo "sweep rc=$?"

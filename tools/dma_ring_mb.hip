@@ -123,6 +123,27 @@ __global__ __launch_bounds__(NTHR, 1) void reg_ring(const char* w, int nslots, u
     out[blockIdx.x * NTHR + tid] = acc.x ^ acc.y ^ acc.z ^ acc.w;
 }
 
+// pure VGPR streaming: no LDS, no barrier; U slots (U x 4 loads per thread) in flight, results xor-ed
+template <int U>
+__global__ __launch_bounds__(NTHR, 2) void reg_pure(const char* w, int nslots, unsigned* out)
+{
+    const int tid = threadIdx.x;
+    u32x4 acc = {0, 0, 0, 0};
+    for (int g0 = 0; g0 < nslots; g0 += U) {
+        u32x4 r[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                r[u][k] = *reinterpret_cast<const u32x4*>(w + (size_t)((g0 + u) % nslots) * SLOT + k * 4096 + tid * 16);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc ^= r[u][k];
+    }
+    out[blockIdx.x * NTHR + tid] = acc.x ^ acc.y ^ acc.z ^ acc.w;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 template <typename K>
@@ -183,6 +204,10 @@ int main()
     check("dma D=6 rot 1", run(dma_ring<6>, 6 * SLOT, dw, nslots, dout, 1 << 20, true, 50));
     check("dma D=6 rot 7", run(dma_ring<6>, 6 * SLOT, dw, nslots, dout, 7 << 20, true, 50));
     check("dma D=6 rot 13", run(dma_ring<6>, 6 * SLOT, dw, nslots, dout, 13 << 20, true, 50));
+    printf("(pure VGPR streaming, no LDS / barrier: checksum not meaningful)\n");
+    check("pure vgpr U=2, 255 WGs", run(reg_pure<2>, 0, dw, nslots, dout, 0, false, 50));
+    check("pure vgpr U=4, 255 WGs", run(reg_pure<4>, 0, dw, nslots, dout, 0, false, 50));
+    check("pure vgpr U=8, 255 WGs", run(reg_pure<8>, 0, dw, nslots, dout, 0, false, 50));
     check("reg D=2 (+1 in LDS)", run(reg_ring<2>, 2 * SLOT, dw, nslots, dout, 0, false, 50));
     check("reg D=4", run(reg_ring<4>, 2 * SLOT, dw, nslots, dout, 0, false, 50));
     check("reg D=7", run(reg_ring<7>, 2 * SLOT, dw, nslots, dout, 0, false, 50));
