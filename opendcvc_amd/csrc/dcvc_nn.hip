@@ -81,6 +81,7 @@ struct HeadParams {
     const float* b1;
     void* a_out;
     long lda;
+    int split;     // adaptor over two sources: stage and reduce one source at a time (half the LDS, same k order)
 };
 
 template <typename T, int MT, int NTW, bool ADAPT>
@@ -93,7 +94,9 @@ __global__ __launch_bounds__(NTHREADS) void dcb_head_kernel(HeadParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Kin = p.src.c0 + p.src.c1;
     const int C = p.C;
-    const int ldx = (Kin > C ? Kin : C) + TR::kPad;   // bufX is reused to stage the output tile
+    const bool split = ADAPT && p.split;
+    const int kstage = split ? (p.src.c0 > p.src.c1 ? p.src.c0 : p.src.c1) : Kin;   // channels staged at a time
+    const int ldx = (kstage > C ? kstage : C) + TR::kPad;   // bufX is reused to stage the output tile
     const int ldy = C + TR::kPad;
     T* bufX = reinterpret_cast<T*>(smem);
     T* bufY = bufX + M * ldx;
@@ -101,15 +104,17 @@ __global__ __launch_bounds__(NTHREADS) void dcb_head_kernel(HeadParams p)
     const int tiles_x = (p.W + TW - 1) / TW;
     const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
 
-    {   // stage the input tile (coalesced 16-byte loads)
-        const int G = Kin / V;
+    // stage channels [cbeg, cbeg + cnt) of the concat input into columns [0, cnt) of bufX (coalesced 16-byte loads)
+    auto stage = [&](int cbeg, int cnt) {
+        const int G = cnt / V;
         for (int it = tid; it < M * G; it += NTHREADS) {
             const int m = it / G, c = (it - m * G) * V;
             const int y = ty0 + m / TW, x = tx0 + m % TW;
             const bool valid = (y < p.H) && (x < p.W);
-            lds_store_vec<T>(bufX, ldx, m, c, load_src<T>(p.src, (long)y * p.W + x, c, valid));
+            lds_store_vec<T>(bufX, ldx, m, c, load_src<T>(p.src, (long)y * p.W + x, cbeg + c, valid));
         }
-    }
+    };
+    stage(0, split ? p.src.c0 : Kin);
     __syncthreads();
 
     int tiles[NTW];
@@ -121,7 +126,15 @@ __global__ __launch_bounds__(NTHREADS) void dcb_head_kernel(HeadParams p)
 
     if (ADAPT) {
         zero_acc(acc);
-        gemm_acc<T, MT, NTW, PF>(acc, bufX, ldx, Kin / KG, reinterpret_cast<const frag_t*>(p.wa), Kin / KG, 0, tiles, lane);
+        if (split) {   // same reduction order as the one-pass form: source 0's channels, then source 1's
+            gemm_acc<T, MT, NTW, PF>(acc, bufX, ldx, p.src.c0 / KG, reinterpret_cast<const frag_t*>(p.wa), Kin / KG, 0, tiles, lane);
+            __syncthreads();
+            stage(p.src.c0, p.src.c1);
+            __syncthreads();
+            gemm_acc<T, MT, NTW, PF>(acc, bufX, ldx, p.src.c1 / KG, reinterpret_cast<const frag_t*>(p.wa), Kin / KG, p.src.c0 / KG, tiles, lane);
+        } else {
+            gemm_acc<T, MT, NTW, PF>(acc, bufX, ldx, Kin / KG, reinterpret_cast<const frag_t*>(p.wa), Kin / KG, 0, tiles, lane);
+        }
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             const int ch0 = tiles[i] * 16 + cq;
@@ -333,21 +346,53 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
             }
             __syncthreads();
             if (slab + 1 < nslab) fetch(slab + 1);
-            for (int m = tid / GS; m < M; m += NTHREADS_ / GS) {
+            // a thread's pixels m0, m0 + MSTEP, ...: the nine tap vectors of the NEXT pixel are requested before the 72
+            // multiply-adds of the current one (two named register sets, no copies), so the LDS latency is paid once per
+            // slab instead of once per pixel
+            constexpr int MSTEP = NTHREADS_ / GS, ITER = (M + MSTEP - 1) / MSTEP;
+            constexpr bool GUARD = M % MSTEP != 0;    // (more threads than pixel x channel-group items: the rest idle)
+            auto taps_load = [&](int m, Vec16 (&v)[9]) {
                 const int my = m / TW, mx = m % TW;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        v[ky * 3 + kx] = *reinterpret_cast<const Vec16*>(bufV + ((my + ky) * HW_ + mx + kx) * lds_s + cs);
+            };
+            auto taps_apply = [&](int m, const Vec16 (&v)[9]) {
                 float s[V];
 #pragma unroll
                 for (int j = 0; j < V; ++j) s[j] = 0.f;
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        fma_vec16<T>(*reinterpret_cast<const Vec16*>(bufV + ((my + ky) * HW_ + mx + kx) * lds_s + cs),
-                                     wtap[ky * 3 + kx], s);
-                    }
+                for (int t = 0; t < 9; ++t) fma_vec16<T>(v[t], wtap[t], s);
 #pragma unroll
                 for (int j = 0; j < V; ++j) s[j] = s[j] + bdv[j];
                 lds_store_vec<T>(bufX, ldx, m, c, pack16<T>(s));
+            };
+            const int m0 = tid / GS;
+            auto live = [&](int m) { return !GUARD || m < M; };
+            Vec16 ta[9], tb[9];
+            if constexpr (MT < 4) {      // 32-pixel tiles keep the plain loop (the second register set would spill there)
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    const int m = m0 + it * MSTEP;
+                    if (live(m)) {
+                        taps_load(m, ta);
+                        taps_apply(m, ta);
+                    }
+                }
+            } else {
+            if (live(m0)) taps_load(m0, ta);
+#pragma unroll
+            for (int it = 0; it < ITER; it += 2) {
+                const int ma = m0 + it * MSTEP, mb = ma + MSTEP, mc = mb + MSTEP;
+                if (it + 1 < ITER && live(mb)) taps_load(mb, tb);
+                if (live(ma)) taps_apply(ma, ta);
+                if (it + 1 < ITER) {
+                    if (it + 2 < ITER && live(mc)) taps_load(mc, ta);
+                    if (live(mb)) taps_apply(mb, tb);
+                }
+            }
             }
             __syncthreads();
         }
@@ -811,9 +856,9 @@ struct dcvc_conv {
 namespace {
 
 template <typename T, int MT>
-size_t head_lds(int kin, int c, bool adapt)
+size_t head_lds(int kstage, int c, bool adapt)    // kstage: input channels staged at a time
 {
-    const int kx = kin > c ? kin : c;
+    const int kx = kstage > c ? kstage : c;
     return (size_t)Tile<MT>::M * ((kx + Traits<T>::kPad) + (adapt ? c + Traits<T>::kPad : 0)) * sizeof(T);
 }
 template <typename T, int MT, int NTW, int NW>
@@ -953,13 +998,17 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     if (ch.head_done) {
         // `a` was written by the previous block's tail
     } else if (h->adapt) {
-        const size_t lds = head_lds<T, MT>(kin, C, true);
+        // two sources: one at a time through LDS (half the staging buffer: a 64-pixel tile of 256 + 256 channels then
+        // leaves room for two workgroups per CU, i.e. half the weight fragments per pixel of the 32-pixel form)
+        hp.split = src.c1 > 0;
+        const int kstage = hp.split ? std::max(src.c0, src.c1) : kin;
+        const size_t lds = head_lds<T, MT>(kstage, C, true);
         if (MT == 4 && lds > 80 * 1024) {
             // a 64-pixel tile of a wide two-source input leaves room for one workgroup per CU (two rounds over
             // a 136x240 map); 32-pixel tiles fit three per CU (97 -> 88 us for head + tail at 256+256 -> 256).
             // Head and tail tile shapes are independent.
             const int grid2 = ((H + Tile<2>::TH - 1) / Tile<2>::TH) * ((W + Tile<2>::TW - 1) / Tile<2>::TW);
-            const size_t lds2 = head_lds<T, 2>(kin, C, true);
+            const size_t lds2 = head_lds<T, 2>(kstage, C, true);
             int rc = set_lds(dcb_head_kernel<T, 2, NTW, true>, lds2);
             if (rc) return rc;
             hipLaunchKernelGGL((dcb_head_kernel<T, 2, NTW, true>), dim3(grid2), dim3(NTHREADS), lds2, st, hp);

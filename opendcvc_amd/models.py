@@ -486,6 +486,13 @@ class DMC(CompressionModel):
     def _extractor_part2(self, x1):
         return L.dcb_chain(self._layers["fe2"], x1)
 
+    def _extractor_both(self, f):
+        """conv1 and conv2 of the feature extractor as ONE chain (encoder side, where both sit in the same captured
+        run): conv2's first block starts in conv1's last tail.  Returns (x1, ctx); same values as part1 + part2."""
+        n = self._layers
+        outs = L.dcb_chain(n["fe1"] + n["fe2"], f, return_all=True)
+        return outs[len(n["fe1"]) - 1], outs[-1]
+
     def _prior_params(self, z_hat, ctx_t, yh, yw):
         """res_prior_param_decoder (video_model.py:279-286) -> [yh, yw, 384] = q_dec | scales | means"""
         n = self._layers
@@ -616,9 +623,8 @@ class DMC(CompressionModel):
                 x1, ctx = ahead[2], ahead[3]
                 ctx_t = self._scaled_context(x1, q["q_feature"])
             else:
-                f = self._adapt(variant, ref_buf)
-                x1, ctx_t = self._extractor_part1(f, q["q_feature"])
-                ctx = self._extractor_part2(x1)
+                x1, ctx = self._extractor_both(self._adapt(variant, ref_buf))
+                ctx_t = self._scaled_context(x1, q["q_feature"])
             e = L.dcb_chain(n["enc_conv2"] + [n["enc_conv3"]], n["enc_conv1"](xin), ctx, quant=q["q_encoder"])
             y = n["enc_down"](e)
             yh, yw = y.shape[0], y.shape[1]
@@ -651,8 +657,7 @@ class DMC(CompressionModel):
         nxt = None
         if self._graphs.enabled:     # next frame's extractor, behind the decoder and under the host coder below
             def extractor_ahead():
-                x1n = L.dcb_chain(self._layers["fe1"], self._layers["fa_p"](fbuf))
-                return x1n, self._extractor_part2(x1n)
+                return self._extractor_both(self._layers["fa_p"](fbuf))
             nxt = (H, W) + tuple(self._graphs.run(("enc_ahead", H, W), extractor_ahead))
 
         # host entropy coding: the previous frame's deferred symbols first (its staging set is reused two frames on)

@@ -135,14 +135,16 @@ class DepthConvBlock:
                 and not prev.shortcut)
 
 
-def dcb_chain(blocks, x0, x1=None, quant=None, out=None):
+def dcb_chain(blocks, x0, x1=None, quant=None, out=None, return_all=False):
     """A run of DepthConvBlocks feeding each other (nn.Sequential of DepthConvBlock in the reference models):
     wherever allowed, block i computes block i+1's pointwise first conv + activation on its output tile while
     that tile is still in LDS, so block i+1 starts at its depthwise stage (one launch and one activation read
     less per block; results are bit-identical to calling the blocks one by one).  x1 goes to the first
-    block, quant / out to the last."""
+    block, quant / out to the last.  return_all: the list of every block's output instead of the last one (a run
+    whose intermediate result is needed elsewhere too, e.g. the feature extractor's x1)."""
     x = x0
     fused = False
+    outs = []
     for i, b in enumerate(blocks):
         last = i + 1 == len(blocks)
         qi = quant if last else None
@@ -150,7 +152,8 @@ def dcb_chain(blocks, x0, x1=None, quant=None, out=None):
         x = b(x, x1 if i == 0 else None, quant=qi, out=out if last else None, head_done=fused, a_slot=i & 1,
               next_block=nxt)
         fused = nxt is not None
-    return x
+        outs.append(x)
+    return outs if return_all else x
 
 
 class Conv2d:
