@@ -315,29 +315,40 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_tail_ps_kernel(Params p)
     halo_load(1);
     Vec16 idf[KS];      // identity fragments of this lane's pixel: idf[ks] = x'[pixel][16 ks + 8 h .. +7] (requested below)
 
-    // depthwise of k-step ks for this lane's pixel: 8 channels x 9 taps -> B fragment
+    // depthwise of k-step ks for this lane's pixel: 8 channels x 9 taps -> B fragment, in two halves: the 20 LDS reads
+    // are issued one MFMA group before the 72 multiply-adds that use them (left to itself hipcc keeps each tap's
+    // read -> wait -> 8 fma together and pays the LDS latency nine times per k-step)
     const int hn0 = ly * HALO_W + lx;                          // halo index of tap (0, 0)
-    auto dw = [&](int ks) -> half8 {
+    Vec16 tap_a[9];
+    int tap_ks = 0;
+    auto dw_load = [&](int ks) {
+        tap_ks = ks;
         const char* hb = halo + ((ks >> 2) & 1) * SLAB_BYTES;
         const int c = 2 * (ks & 3) + h;
-        float s[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] = 0.f;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int n = hn0 + ky * HALO_W + kx;
-                const Vec16 av = *reinterpret_cast<const Vec16*>(hb + n * 128 + ((c ^ ((n >> 1) & 7)) << 4));
-                const Vec16 wv = *reinterpret_cast<const Vec16*>(tbl + CF::T_WD + ((ky * 3 + kx) * C + ks * 16 + h * 8) * 2);
-                fma_vec16<half_t>(av, wv, s);
+                tap_a[ky * 3 + kx] = *reinterpret_cast<const Vec16*>(hb + n * 128 + ((c ^ ((n >> 1) & 7)) << 4));
             }
-        const floatx4 b0 = *reinterpret_cast<const floatx4*>(tbl + CF::T_BD + (ks * 16 + h * 8) * 4);
-        const floatx4 b1 = *reinterpret_cast<const floatx4*>(tbl + CF::T_BD + (ks * 16 + h * 8 + 4) * 4);
+    };
+    auto dw_math = [&]() -> half8 {      // (the tap weights and the bias - broadcast reads of the tables - are read here)
+        const int ks = tap_ks;
+        Vec16 tap_w[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) tap_w[t] = *reinterpret_cast<const Vec16*>(tbl + CF::T_WD + (t * C + ks * 16 + h * 8) * 2);
+        const floatx4 tap_b0 = *reinterpret_cast<const floatx4*>(tbl + CF::T_BD + (ks * 16 + h * 8) * 4);
+        const floatx4 tap_b1 = *reinterpret_cast<const floatx4*>(tbl + CF::T_BD + (ks * 16 + h * 8 + 4) * 4);
+        float s[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) fma_vec16<half_t>(tap_a[t], tap_w[t], s);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            s[j] = s[j] + b0[j];
-            s[j + 4] = s[j + 4] + b1[j];
+            s[j] = s[j] + tap_b0[j];
+            s[j + 4] = s[j + 4] + tap_b1[j];
         }
         return pack8(s);
     };
@@ -366,7 +377,8 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_tail_ps_kernel(Params p)
     halo_commit(1);
     read_q(ic<0>{});
     read_q(ic<1>{});
-    half8 d_cur = dw(0);
+    dw_load(0);
+    half8 d_cur = dw_math();
     static_for<NT>([&](auto ii) {                              // slot i: k-step 2 i (groups 0, 1), 2 i + 1 (groups 2, 3)
         constexpr int i = decltype(ii)::value;
         if constexpr (i == 0) {                                // (the barrier above was step 0's)
@@ -374,8 +386,17 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_tail_ps_kernel(Params p)
         } else {
             ring_step(ii, i);
             // slab s+1 is written at slot 2 s (it is first read one k-step before slot 2 s + 2) and requested at 2 s - 1
+#ifdef DCVC_DIAG
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long th0 = __builtin_amdgcn_s_memtime();
+#endif
             if constexpr ((i & 1) == 0 && i / 2 + 1 < CF::NSLAB) halo_commit(i / 2 + 1);
             if constexpr ((i & 1) == 1 && (i + 1) / 2 + 1 < CF::NSLAB) halo_load((i + 1) / 2 + 1);
+#ifdef DCVC_DIAG
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            t_lds += __builtin_amdgcn_s_memtime() - th0;       // (GEMM2 phase: reported as "lds_drain" = halo staging)
+#endif
         }
         if constexpr (i == (NT > 4 ? NT - 4 : 0)) {           // x' is needed right after this GEMM: request it 4 steps ahead
 #pragma unroll
@@ -384,16 +405,19 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_tail_ps_kernel(Params p)
                 if (pvalid) idf[ks] = *reinterpret_cast<const Vec16*>(ident + gpix * p.ldi + ks * 16 + h * 8);
             }
         }
-        const half8 d_n1 = dw(2 * i + 1);
-        half8 d_n2 = d_n1;
+        half8 d_n1 = d_cur, d_n2 = d_cur;
         slot_groups(ii, [&](auto jc, const half8 (&F)[GS]) {
             constexpr int j = decltype(jc)::value;
+            if constexpr (j == 0) dw_load(2 * i + 1);                              // taps of the slot's second k-step
             if constexpr (j == 2) {
                 d_cur = d_n1;
-                d_n2 = dw(2 * i + 2 < KS ? 2 * i + 2 : KS - 1);
+                dw_load(2 * i + 2 < KS ? 2 * i + 2 : KS - 1);                      // taps of the next slot's first k-step
             }
 #pragma unroll
             for (int t = 0; t < GS; ++t) acc[(j & 1) * GS + t] = mfma32(F[t], d_cur, acc[(j & 1) * GS + t]);
+            if constexpr (j == 0 || j == 2) __builtin_amdgcn_sched_barrier(0);     // reads issued here, used one group later
+            if constexpr (j == 1) d_n1 = dw_math();
+            if constexpr (j == 3) d_n2 = dw_math();
         });
         d_cur = d_n2;
     });
