@@ -415,7 +415,12 @@ class DMC(CompressionModel):
         D, C2, R = L.DepthConvBlock, L.Conv2d, L.ResidualBlockWithStride2
         n = {}
         n["fa_i"] = D(sd, "feature_adaptor_i", dt)
-        n["fa_p"] = C2(sd, "feature_adaptor_p", dt)
+        # feature_adaptor_p (1x1, 256 -> 256) followed by the extractor's first DepthConvBlock IS a block with an
+        # adaptor: one head launch computes f = adaptor_p(ref) (written out as the block's identity branch) and the
+        # first conv + activation on the tile still in LDS - same kernels' arithmetic, same roundings as the two launches
+        fused = {"m" + k[len("feature_extractor.conv1.0"):]: v for k, v in sd.items() if k.startswith("feature_extractor.conv1.0.")}
+        fused["m.adaptor.weight"], fused["m.adaptor.bias"] = sd["feature_adaptor_p.weight"], sd["feature_adaptor_p.bias"]
+        n["fe1_p"] = [D(fused, "m", dt)]
         n["fe1"] = [D(sd, f"feature_extractor.conv1.{i}", dt) for i in range(2)]
         n["fe2"] = [D(sd, f"feature_extractor.conv2.{i}", dt) for i in range(4)]
         n["enc_conv1"] = C2(sd, "encoder.conv1", dt)
@@ -472,8 +477,17 @@ class DMC(CompressionModel):
             self.reset_ref_feature()
 
     # ---- sub-networks
-    def _extractor_part1(self, f, q_feature):
-        x1 = L.dcb_chain(self._layers["fe1"], f)
+    def _fe1(self, variant):
+        """conv1 of the feature extractor as seen from the reference buffer: after a P frame its first block carries
+        feature_adaptor_p as its adaptor (fe1_p); after an I frame / a refresh feature_adaptor_i is a block of its own"""
+        n = self._layers
+        return n["fe1_p"] + n["fe1"][1:] if variant == "p" else [n["fa_i"]] + n["fe1"]
+
+    def _fe_input(self, variant, ref_buf):
+        return ref_buf if variant == "p" else self._unshuffle8(ref_buf)
+
+    def _extractor_part1(self, variant, ref_buf, q_feature):
+        x1 = L.dcb_chain(self._fe1(variant), self._fe_input(variant, ref_buf))
         return x1, self._scaled_context(x1, q_feature)
 
     def _scaled_context(self, x1, q_feature):
@@ -486,12 +500,12 @@ class DMC(CompressionModel):
     def _extractor_part2(self, x1):
         return L.dcb_chain(self._layers["fe2"], x1)
 
-    def _extractor_both(self, f):
-        """conv1 and conv2 of the feature extractor as ONE chain (encoder side, where both sit in the same captured
-        run): conv2's first block starts in conv1's last tail.  Returns (x1, ctx); same values as part1 + part2."""
-        n = self._layers
-        outs = L.dcb_chain(n["fe1"] + n["fe2"], f, return_all=True)
-        return outs[len(n["fe1"]) - 1], outs[-1]
+    def _extractor_both(self, variant, ref_buf):
+        """feature adaptor, conv1 and conv2 of the feature extractor as ONE chain (encoder side, where they sit in the
+        same captured run): every block starts in its predecessor's tail.  Returns (x1, ctx); same values as part1 + part2."""
+        blocks = self._fe1(variant)
+        outs = L.dcb_chain(blocks + self._layers["fe2"], self._fe_input(variant, ref_buf), return_all=True)
+        return outs[len(blocks) - 1], outs[-1]
 
     def _prior_params(self, z_hat, ctx_t, yh, yw):
         """res_prior_param_decoder (video_model.py:279-286) -> [yh, yw, 384] = q_dec | scales | means"""
@@ -569,12 +583,6 @@ class DMC(CompressionModel):
     def _feature_buf(self, shape, dtype, device):
         return self._buffer("feature", shape, dtype, device)
 
-    def _adapt(self, variant, ref_buf):
-        n = self._layers
-        if variant == "i":
-            return n["fa_i"](self._unshuffle8(ref_buf))
-        return n["fa_p"](ref_buf)
-
     def _code_symbols(self, job):
         """host: entropy-codes one frame's symbols (waits for their copy to the pinned staging first)"""
         ready, hz, hp, nz, nsym, zhw, qp = job
@@ -623,7 +631,7 @@ class DMC(CompressionModel):
                 x1, ctx = ahead[2], ahead[3]
                 ctx_t = self._scaled_context(x1, q["q_feature"])
             else:
-                x1, ctx = self._extractor_both(self._adapt(variant, ref_buf))
+                x1, ctx = self._extractor_both(variant, ref_buf)
                 ctx_t = self._scaled_context(x1, q["q_feature"])
             e = L.dcb_chain(n["enc_conv2"] + [n["enc_conv3"]], n["enc_conv1"](xin), ctx, quant=q["q_encoder"])
             y = n["enc_down"](e)
@@ -657,7 +665,7 @@ class DMC(CompressionModel):
         nxt = None
         if self._graphs.enabled:     # next frame's extractor, behind the decoder and under the host coder below
             def extractor_ahead():
-                return self._extractor_both(self._layers["fa_p"](fbuf))
+                return self._extractor_both("p", fbuf)
             nxt = (H, W) + tuple(self._graphs.run(("enc_ahead", H, W), extractor_ahead))
 
         # host entropy coding: the previous frame's deferred symbols first (its staging set is reused two frames on)
@@ -703,7 +711,7 @@ class DMC(CompressionModel):
         zb = ec.pinned("z_dec", nz)
 
         x1, ctx_t = self._graphs.run(("dec_0",) + key,
-                                     lambda: self._extractor_part1(self._adapt(variant, ref_buf), q["q_feature"]))
+                                     lambda: self._extractor_part1(variant, ref_buf, q["q_feature"]))
         ec.get_decoded(zb.view(np.int8, nz))
 
         def after_z():
