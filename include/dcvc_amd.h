@@ -55,6 +55,7 @@ int dcvc_device_count(void);
  *   w3 [4C][C], w4 [C][2C], biases [C] / [4C].
  * C and Cin are LOGICAL sizes; rows of the activation buffers hold round_up(.,32) channels. */
 typedef struct dcvc_dcb dcvc_dcb;
+typedef struct dcvc_conv dcvc_conv;   /* dense convolution layer, declared below */
 int dcvc_dcb_create(int dtype, int cin, int c, int shortcut, const float* adaptor_w,
                     const float* adaptor_b, const float* w1, const float* b1, const float* wd,
                     const float* bd, const float* w2, const float* b2, const float* w3,
@@ -82,6 +83,17 @@ int dcvc_dcb_forward_chained(const dcvc_dcb* h, const void* x0, int64_t ld0, int
                              int64_t ldo, void* scratch, void* stream, int head_done, int a_slot,
                              const dcvc_dcb* next);
 
+/* A run of DepthConvBlocks that ends in a 1x1 convolution of the same width (decoder.conv2 video_model.py:109, the
+ * last layer of y_prior_fusion :199 and y_spatial_prior :212): the last block also computes that convolution
+ * (bias, or bias * quant as dcvc_conv_forward would) on its output tile while the tile is still on the CU and writes
+ * ONLY the convolution's output (conv_out, row stride ldco) - one launch and two passes over the feature map less;
+ * the values are bit-identical to dcvc_dcb_forward_chained(..., next = NULL) followed by dcvc_conv_forward.
+ * Needs: block without shortcut, conv 1x1 / stride 1 / cin = cout = the block's width. */
+int dcvc_dcb_forward_then_conv(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, const void* x1,
+                               int64_t ld1, int c1, int H, int W, void* scratch, void* stream,
+                               int head_done, int a_slot, const dcvc_conv* conv, const float* conv_quant,
+                               void* conv_out, int64_t ldco);
+
 /* Measurement aid (bench.py roofline leg): runs the block `iters` times on `stream` with HIP events
  * recorded on that stream around each of its two kernels; returns the mean durations in ms. */
 int dcvc_dcb_profile(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, int H, int W, void* out,
@@ -93,7 +105,6 @@ int dcvc_dcb_profile(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, int
  * epilogue kernels bias_quant_cuda / bias_pixel_shuffle_2_cuda (kernel.cu:534,697).
  * w: HOST float32 [Cout][Cin][KH][KW]; b: HOST float32 [Cout].  For DCVC_EPI_SHUFFLE2 `cout` is
  * the conv's channel count (4 x the shuffled channel count). */
-typedef struct dcvc_conv dcvc_conv;
 int dcvc_conv_create(int dtype, int cin, int cout, int kh, int kw, int stride, int pad, int epilogue,
                      const float* w, const float* b, dcvc_conv** out);
 void dcvc_conv_destroy(dcvc_conv* h);

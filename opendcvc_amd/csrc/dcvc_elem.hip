@@ -18,10 +18,19 @@ __device__ __forceinline__ float ld(const T* p, int64_t i)
 {
     return (float)p[i];
 }
+// fp32 VALUE -> storage type.  The empty asm hides the value's producer, so the compiler cannot fold the preceding
+// fp32 add / multiply into v_fma_mixlo_f16 (one rounding) in one kernel and leave add + cvt (two roundings) in another:
+// the encoder's and the decoder's y_hat kernels must round alike (see Traits<half_t>::from_f, gemm_core.hpp).
+template <typename T>
+__device__ __forceinline__ T to_t(float v)
+{
+    asm("" : "+v"(v));
+    return (T)v;
+}
 template <typename T>
 __device__ __forceinline__ void st(T* p, int64_t i, float v)
 {
-    p[i] = (T)v;
+    p[i] = to_t<T>(v);
 }
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi)
@@ -242,7 +251,7 @@ __global__ void frame_to_yuv420_kernel(const T* x, int HP, int WP, int H, int W,
     if (i >= ny + 2 * nc) return;
     if (i < ny) {
         const int xw = (int)(i % W), y = (int)(i / W);
-        const float s = (float)(T)(ld(x, (int64_t)y * WP + xw) * 255.0f);   // product rounded to the storage type, as torch does
+        const float s = (float)to_t<T>(ld(x, (int64_t)y * WP + xw) * 255.0f);   // product rounded to the storage type, as torch does
         yp[i] = (uint8_t)dcvc_roundf(clampf(s, 0.f, 255.f));
         return;
     }
@@ -254,8 +263,8 @@ __global__ void frame_to_yuv420_kernel(const T* x, int HP, int WP, int H, int W,
     const T* pl = x + (int64_t)c * HP * WP;
     const float a = ld(pl, (int64_t)(2 * y) * WP + 2 * xw), b = ld(pl, (int64_t)(2 * y) * WP + 2 * xw + 1);
     const float d = ld(pl, (int64_t)(2 * y + 1) * WP + 2 * xw), e = ld(pl, (int64_t)(2 * y + 1) * WP + 2 * xw + 1);
-    const float m = (float)(T)(((a + b) + (d + e)) * 0.25f);                 // avg_pool2d(2) result in the storage type
-    float s = clampf((float)(T)(m * 255.0f), 0.f, 255.f);
+    const float m = (float)to_t<T>(((a + b) + (d + e)) * 0.25f);                 // avg_pool2d(2) result in the storage type
+    float s = clampf((float)to_t<T>(m * 255.0f), 0.f, 255.f);
     if (round_uv) s = dcvc_roundf(s);
     (c == 1 ? up : vp)[k] = (uint8_t)s;                                      // truncation like `.to(uint8)`
 }
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(EB) void prior_enc_kernel(PriorEncArgs a)
             if (use_thres && !(s > a.thres)) v = v * 0.f;
             v = clampf(v, -128.f, 127.f);
             // T-rounded like the reference, whose y_hat_k tensors are stored in the model dtype
-            const float yh = (float)(T)(v + m);
+            const float yh = (float)to_t<T>(v + m);
             st(hout, p * a.ldho + ch, a.step == 0 ? yh : prev + yh);
             const float scl = clampf(s, kScaleMin, kScaleMax);
             const bool keep = !use_thres || (scl > a.thres);
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(EB) void prior_dec_restore_kernel(int n_groups, int
                 st(hout, p * ldho + ch, prev);
                 continue;
             }
-            const float yh = (float)(T)((float)sp[cc * PT + pl] + ld(mu, p * ldm + ch));
+            const float yh = (float)to_t<T>((float)sp[cc * PT + pl] + ld(mu, p * ldm + ch));
             st(hout, p * ldho + ch, step == 0 ? yh : prev + yh);
         }
     }
@@ -572,7 +581,7 @@ __global__ void op_bias_wsilu_dw_kernel(const T* x, const T* w, const T* bias, i
             const int ix = xw + kx - 1;
             if (ix < 0 || ix >= W) continue;
             // activation rounded to the storage type like the reference's smem tile inputs
-            const float av = (float)(T)dcvc_wsiluf(ld(x, ((int64_t)c * H + iy) * W + ix) + b);
+            const float av = (float)to_t<T>(dcvc_wsiluf(ld(x, ((int64_t)c * H + iy) * W + ix) + b));
             s = DCVC_FMAF(av, ld(w, c * 9 + ky * 3 + kx), s);
         }
     }

@@ -209,6 +209,11 @@ struct TailParams {
     const float* nb1;
     void* na_out;
     long nlda;
+    // ... or a 1x1 convolution of the same width that consumes the block's output (decoder.conv2, the last conv of
+    // y_prior_fusion / y_spatial_prior): nplain = 1 -> na_out = (W r + b) [* nq], no activation; out may then be NULL
+    int nplain;
+    const float* nq;
+    int n_log;
     int ablate;          // debug: bit0 skip dw, bit1 skip GEMM2, bit2 skip FFN GEMM3, bit3 skip FFN GEMM4
     unsigned long long* stamps;   // diagnostic build only (DCVC_STAMPS): 8 cycle counters per workgroup
 };
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
     }
     __syncthreads();
     T* out = reinterpret_cast<T*>(p.out);
-    for (int it = tid; it < M * GC; it += NTHREADS_) {
+    for (int it = tid; out != nullptr && it < M * GC; it += NTHREADS_) {     // (out == NULL: only the fused conv's output is wanted)
         const int m = it / GC, c = (it - m * GC) * V;
         const int y = ty0 + m / TW, x = tx0 + m % TW;
         if (y < p.H && x < p.W) {
@@ -573,17 +578,38 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
         zero_acc(acc1);
         gemm_acc<T, MT, NTW, PF>(acc1, bufX, ldx, C / KG, reinterpret_cast<const frag_t*>(p.nw1), C / KG, 0, wtiles, lane);
         __syncthreads();   // every wave has finished reading r
+        if (p.nplain) {      // fused 1x1 conv: same epilogue as conv_kernel (bias, or bias * q), no activation
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-            const int ch0 = tiles[i] * 16 + cq;
-            const floatx4 bias = load_f4(p.nb1 + wtiles[i] * 16 + cq);
-            if (tile_exists(i)) {
+            for (int i = 0; i < NTW; ++i) {
+                const int ch0 = tiles[i] * 16 + cq;
+                const floatx4 bias = load_f4(p.nb1 + wtiles[i] * 16 + cq);
+                floatx4 qv = {1.f, 1.f, 1.f, 1.f};
+                if (p.nq != nullptr) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    floatx4 v = acc1[m][i] + bias;
+                    for (int r = 0; r < 4; ++r) qv[r] = (ch0 + r) < p.n_log ? p.nq[ch0 + r] : 1.0f;
+                }
+                if (tile_exists(i)) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = TR::gate(v[r]);
-                    lds_store_quad<T>(bufX, ldx, m * 16 + pl, ch0, v);
+                    for (int m = 0; m < MT; ++m) {
+                        floatx4 v = acc1[m][i] + bias;
+                        if (p.nq != nullptr) v = v * qv;
+                        lds_store_quad<T>(bufX, ldx, m * 16 + pl, ch0, v);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                const int ch0 = tiles[i] * 16 + cq;
+                const floatx4 bias = load_f4(p.nb1 + wtiles[i] * 16 + cq);
+                if (tile_exists(i)) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        floatx4 v = acc1[m][i] + bias;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = TR::gate(v[r]);
+                        lds_store_quad<T>(bufX, ldx, m * 16 + pl, ch0, v);
+                    }
                 }
             }
         }
@@ -967,6 +993,11 @@ static bool use_ps(const dcvc_dcb* h, int H, int W)
 struct ChainArgs {
     int head_done = 0, a_slot = 0;
     const dcvc_dcb* next = nullptr;
+    // or: a 1x1 conv of the same width fused behind the block (its output replaces the block's)
+    const dcvc_conv* conv = nullptr;
+    const float* conv_q = nullptr;
+    void* conv_out = nullptr;
+    int64_t ldco = 0;
 };
 
 template <typename T, int MT, int NTW>
@@ -1051,10 +1082,18 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         tp.nb1 = (const float*)ch.next->b1.p;
         tp.na_out = a_next;
         tp.nlda = C;
+    } else if (ch.conv) {
+        tp.nw1 = ch.conv->w.p;
+        tp.nb1 = (const float*)ch.conv->b.p;
+        tp.na_out = ch.conv_out;
+        tp.nlda = ch.ldco;
+        tp.nplain = 1;
+        tp.nq = ch.conv_q;
+        tp.n_log = ch.conv->cout;
     }
 #ifdef DCVC_EXPERIMENTAL_PS
     if constexpr (sizeof(T) == 2) {
-        if (use_ps(h, H, W) && (!ch.next || ch.next->ps)) {
+        if (use_ps(h, H, W) && (!ch.next || ch.next->ps) && !ch.conv) {
             ps::Params pp{};
             pp.a = tp.a;
             pp.lda = tp.lda;
@@ -1385,6 +1424,40 @@ int dcvc_dcb_forward_chained(const dcvc_dcb* h, const void* x0, int64_t ld0, int
     ch.a_slot = a_slot;
     ch.next = next;
     return run_dcb(h, src, H, W, quant, out, ldo, scratch, st, nullptr, ch);
+}
+
+int dcvc_dcb_forward_then_conv(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, const void* x1, int64_t ld1, int c1,
+                               int H, int W, void* scratch, void* stream, int head_done, int a_slot,
+                               const dcvc_conv* conv, const float* conv_quant, void* conv_out, int64_t ldco)
+{
+    DCVC_REQUIRE(h && x0 && scratch && conv && conv_out, "dcvc_dcb_forward_then_conv: null pointer");
+    DCVC_REQUIRE(!head_done || !h->adapt, "dcvc_dcb_forward_then_conv: a block with adaptor computes its own head");
+    DCVC_REQUIRE(!h->shortcut, "dcvc_dcb_forward_then_conv: a block with shortcut cannot feed a fused conv");
+    DCVC_REQUIRE(conv->dtype == h->dtype && conv->kh == 1 && conv->kw == 1 && conv->stride == 1 && conv->pad == 0 &&
+                     conv->cin_p == h->c_p && conv->n_p == h->c_p && conv->cin == h->c &&
+                     (conv->epi == DCVC_EPI_BIAS || conv->epi == DCVC_EPI_BIAS_QUANT),
+                 "dcvc_dcb_forward_then_conv: the conv must be 1x1, stride 1, of the block's width (%d -> %d given, block %d), "
+                 "epilogue bias or bias*quant", conv->cin, conv->cout, h->c);
+    DCVC_REQUIRE((conv->epi == DCVC_EPI_BIAS_QUANT) == (conv_quant != nullptr), "dcvc_dcb_forward_then_conv: quant vector / epilogue mismatch");
+    DCVC_REQUIRE(H > 0 && W > 0, "dcvc_dcb_forward_then_conv: empty input %dx%d", H, W);
+    DCVC_REQUIRE(c0 % 32 == 0 && c1 % 32 == 0 && c0 + c1 == h->cin_p,
+                 "dcvc_dcb_forward_then_conv: input channels %d+%d do not match the block (%d physical)", c0, c1, h->cin_p);
+    DCVC_REQUIRE((x1 != nullptr) == (c1 > 0), "dcvc_dcb_forward_then_conv: x1/c1 mismatch");
+    DCVC_REQUIRE(h->adapt || c1 == 0, "dcvc_dcb_forward_then_conv: a block without adaptor takes a single source");
+    DCVC_REQUIRE(ld0 >= c0 && ldco >= h->c_p && (c1 == 0 || ld1 >= c1), "dcvc_dcb_forward_then_conv: row stride too small");
+    const size_t es = dcvc::elem_size(h->dtype);
+    DCVC_REQUIRE(((uintptr_t)x0 % 16) == 0 && (ld0 * es) % 16 == 0 && ((uintptr_t)conv_out % 16) == 0 && (ldco * es) % 16 == 0 &&
+                     (c1 == 0 || (((uintptr_t)x1 % 16) == 0 && (ld1 * es) % 16 == 0)),
+                 "dcvc_dcb_forward_then_conv: buffers must be 16-byte aligned");
+    SrcPair src{x0, (long)ld0, c0, x1, (long)ld1, c1};
+    ChainArgs ch;
+    ch.head_done = head_done;
+    ch.a_slot = a_slot;
+    ch.conv = conv;
+    ch.conv_q = conv_quant;
+    ch.conv_out = conv_out;
+    ch.ldco = ldco;
+    return run_dcb(h, src, H, W, nullptr, nullptr, 0, scratch, (hipStream_t)stream, nullptr, ch);
 }
 
 int dcvc_dcb_profile(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, int H, int W, void* out, int64_t ldo,

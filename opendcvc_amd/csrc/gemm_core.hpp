@@ -48,7 +48,17 @@ struct Traits<half_t> {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ float to_f(half_t v) { return (float)v; }
-    static __device__ __forceinline__ half_t from_f(float v) { return (half_t)v; }
+    // fp32 -> fp16 (RNE) of the fp32 VALUE.  The empty asm hides the value's producer: otherwise the compiler folds a
+    // preceding fp32 multiply into v_fma_mixlo_f16 (product rounded ONCE, straight to fp16) for whichever elements its
+    // scheduler picks, and v_pk_mul_f32 + v_cvt_pk_f16_f32 (rounded twice) for the rest - a choice that differs from
+    // kernel to kernel, so the same gate computed in dcb_head_kernel and in a fused tail disagreed by one fp16 ulp on
+    // values within 2 fp32 ulps of a rounding midpoint (2 of 4 M).  With it every store is the two-step rounding the
+    // oracle models, whatever kernel it sits in.
+    static __device__ __forceinline__ half_t from_f(float v)
+    {
+        asm("" : "+v"(v));   // free: dcb_tail_kernel 51.5 us with it, 54.6 us without on the same box (tools/kbench.py)
+        return (half_t)v;
+    }
     // fp16 mode: hardware exp2 / rcp (about 1 ulp in fp32, far below the fp16 storage rounding);
     // 5 VALU instructions instead of ~35 for the reproducible dcvc_wsiluf.
     static __device__ __forceinline__ float wsilu(float x)
@@ -316,7 +326,7 @@ template <>
 __device__ __forceinline__ void lds_store_quad<half_t>(half_t* buf, int ld, int row, int ch0, const floatx4& v)
 {
     typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-    half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    half4 h = {Traits<half_t>::from_f(v[0]), Traits<half_t>::from_f(v[1]), Traits<half_t>::from_f(v[2]), Traits<half_t>::from_f(v[3])};
     *reinterpret_cast<half4*>(buf + row * ld + ch0) = h;
 }
 template <>
@@ -368,7 +378,7 @@ __device__ __forceinline__ Vec16 pack16<half_t>(const float (&f)[8])
 {
     half8 h;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) h[j] = (half_t)f[j];
+    for (int j = 0; j < 8; ++j) h[j] = Traits<half_t>::from_f(f[j]);
     return __builtin_bit_cast(Vec16, h);
 }
 template <>
@@ -387,7 +397,7 @@ template <>
 __device__ __forceinline__ void global_store_quad<half_t>(half_t* p, const floatx4& v)
 {
     typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-    half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    half4 h = {Traits<half_t>::from_f(v[0]), Traits<half_t>::from_f(v[1]), Traits<half_t>::from_f(v[2]), Traits<half_t>::from_f(v[3])};
     *reinterpret_cast<half4*>(p) = h;
 }
 template <>

@@ -502,7 +502,8 @@ class DMC(CompressionModel):
 
     def _extractor_both(self, variant, ref_buf):
         """feature adaptor, conv1 and conv2 of the feature extractor as ONE chain (encoder side, where they sit in the
-        same captured run): every block starts in its predecessor's tail.  Returns (x1, ctx); same values as part1 + part2."""
+        same captured run): every block starts in its predecessor's tail.  Returns (x1, ctx); same values, bit for bit,
+        as part1 + part2 on the decoder (test_chained_blocks_equal_separate_calls and the enc/dec context tests)."""
         blocks = self._fe1(variant)
         outs = L.dcb_chain(blocks + self._layers["fe2"], self._fe_input(variant, ref_buf), return_all=True)
         return outs[len(blocks) - 1], outs[-1]
@@ -517,16 +518,15 @@ class DMC(CompressionModel):
         else:
             self._crop(n["hyper_dec"][2](h), yh, yw, out=cat[:, :, :arch.DMC_CH_Y])
         n["temporal"](ctx_t, out=cat[:, :, arch.DMC_CH_Y:])
-        return n["fusion_out"](L.dcb_chain(n["fusion"], cat))
+        return L.dcb_chain(n["fusion"], cat, then_conv=n["fusion_out"])          # (the last conv runs in the last tail)
 
     def _spatial_prior(self, y_hat, params):
         n = self._layers
-        return n["spatial_out"](L.dcb_chain(n["spatial"], y_hat, params))
+        return L.dcb_chain(n["spatial"], y_hat, params, then_conv=n["spatial_out"])
 
     def _decoder(self, y_hat, ctx, q_decoder, out=None):
         n = self._layers
-        f = L.dcb_chain(n["dec_conv1"], n["dec_up"](y_hat), ctx)
-        return n["dec_conv2"](f, quant=q_decoder, out=out)
+        return L.dcb_chain(n["dec_conv1"], n["dec_up"](y_hat), ctx, then_conv=n["dec_conv2"], conv_quant=q_decoder, out=out)
 
     def _recon(self, feature, q_recon):
         n = self._layers
@@ -807,11 +807,11 @@ class DMCI(CompressionModel):
     def _prior_params(self, z_hat, yh, yw):
         n = self._layers
         p = n["hyper_dec"][2](n["hyper_dec"][1](n["hyper_dec"][0](z_hat)))
-        return self._crop(n["fusion_out"](L.dcb_chain(n["fusion"], p)), yh, yw)     # [yh, yw, 544]: q_enc q_dec | scales | means | pad
+        return self._crop(L.dcb_chain(n["fusion"], p, then_conv=n["fusion_out"]), yh, yw)     # [yh, yw, 544]: q_enc q_dec | scales | means | pad
 
     def _spatial_prior(self, y_hat, common, step):
         n = self._layers
-        return n["spatial_out"](L.dcb_chain([n["sp_adaptor"][step]] + n["spatial"], y_hat, common))
+        return L.dcb_chain([n["sp_adaptor"][step]] + n["spatial"], y_hat, common, then_conv=n["spatial_out"])
 
     def compress(self, x, qp):
         """image_model.py:143-185 + compress_prior_4x (common_model.py:206-256).  Two captured runs, like DMC:

@@ -129,30 +129,57 @@ class DepthConvBlock:
                                          next_block.h if next_block is not None else None), "dcvc_dcb_forward")
         return out
 
+    def then_conv(self, x0, x1, conv, conv_quant=None, out=None, head_done=False, a_slot=0):
+        """This block followed by a 1x1 conv of the same width (dcvc_dcb_forward_then_conv): only the conv's output
+        is written.  conv.fusable_after(self) must hold."""
+        L = _lib.lib()
+        H, W, c0, ld0 = _geom(x0)
+        c1, ld1 = 0, 0
+        if x1 is not None:
+            H1, W1, c1, ld1 = _geom(x1)
+            if (H1, W1) != (H, W):
+                raise DcvcError("concat inputs differ in size")
+        if out is None:
+            out = torch.empty((H, W, conv.cout_p), dtype=self.dtype, device=x0.device)
+        Ho, Wo, co, ldo = _geom(out)
+        if (Ho, Wo) != (H, W) or co < conv.cout_p or out.dtype != self.dtype or x0.dtype != self.dtype:
+            raise DcvcError(f"output view {tuple(out.shape)} does not fit the fused conv's output")
+        scratch = Scratch.get(L.dcvc_dcb_scratch_bytes(self.h, H, W), x0.device)
+        check(L.dcvc_dcb_forward_then_conv(self.h, _p(x0), ld0, c0, _p(x1), ld1, c1, H, W, _p(scratch), _stream(),
+                                           int(head_done), int(a_slot), conv.h, _p(conv_quant), _p(out), ldo),
+              "dcvc_dcb_forward_then_conv")
+        return out
+
     def can_follow(self, prev, prev_quant):
         """True if `prev` (run with quant step `prev_quant`) may compute this block's first conv in its epilogue"""
         return (not self.has_adaptor and self.c_p == prev.c_p and self.dtype == prev.dtype and prev_quant is None
                 and not prev.shortcut)
 
 
-def dcb_chain(blocks, x0, x1=None, quant=None, out=None, return_all=False):
+def dcb_chain(blocks, x0, x1=None, quant=None, out=None, return_all=False, then_conv=None, conv_quant=None):
     """A run of DepthConvBlocks feeding each other (nn.Sequential of DepthConvBlock in the reference models):
     wherever allowed, block i computes block i+1's pointwise first conv + activation on its output tile while
     that tile is still in LDS, so block i+1 starts at its depthwise stage (one launch and one activation read
     less per block; results are bit-identical to calling the blocks one by one).  x1 goes to the first
     block, quant / out to the last.  return_all: the list of every block's output instead of the last one (a run
-    whose intermediate result is needed elsewhere too, e.g. the feature extractor's x1)."""
+    whose intermediate result is needed elsewhere too, e.g. the feature extractor's x1).
+    then_conv: a Conv2d applied to the run's result (conv_quant: its quant vector; `out` then is the conv's output):
+    where the shapes allow, the last block computes it on its output tile and the run's own result is never written."""
     x = x0
     fused = False
     outs = []
     for i, b in enumerate(blocks):
         last = i + 1 == len(blocks)
+        if last and then_conv is not None and quant is None and not return_all and then_conv.fusable_after(b):
+            return b.then_conv(x, x1 if i == 0 else None, then_conv, conv_quant, out=out, head_done=fused, a_slot=i & 1)
         qi = quant if last else None
         nxt = None if last or not blocks[i + 1].can_follow(b, qi) else blocks[i + 1]
-        x = b(x, x1 if i == 0 else None, quant=qi, out=out if last else None, head_done=fused, a_slot=i & 1,
+        x = b(x, x1 if i == 0 else None, quant=qi, out=out if (last and then_conv is None) else None, head_done=fused, a_slot=i & 1,
               next_block=nxt)
         fused = nxt is not None
         outs.append(x)
+    if then_conv is not None:
+        return then_conv(x, quant=conv_quant, out=out)
     return outs if return_all else x
 
 
@@ -182,6 +209,12 @@ class Conv2d:
                 _lib.lib().dcvc_conv_destroy(self.h)
         except Exception:
             pass
+
+    def fusable_after(self, block):
+        """True if this conv may be computed in `block`'s tail (dcvc_dcb_forward_then_conv)"""
+        return (self.kh == 1 and self.kw == 1 and self.stride == 1 and self.pad == 0 and self.cin == block.c and
+                self.cin_p == block.c_p and self.cout_p == block.c_p and self.dtype == block.dtype and
+                not block.shortcut and self.epi in (_lib.EPI_BIAS, _lib.EPI_BIAS_QUANT))
 
     def out_hw(self, H, W):
         Ho = (H + 2 * self.pad - self.kh) // self.stride + 1

@@ -129,7 +129,9 @@ def test_depth_conv_block_large_map_fp16(c):
 @pytest.mark.parametrize("c,hw", [(256, (21, 19)), (128, (9, 33)), (368, (12, 11)), (320, (101, 123))])
 def test_chained_blocks_equal_separate_calls(c, hw, dtype):
     """dcb_chain (the next block's first conv computed in the previous block's epilogue) is bit-identical to
-    calling the blocks one by one, in both modes; a block with a quant step or a different width ends a chain."""
+    calling the blocks one by one, in both modes; a block with a quant step or a different width ends a chain.
+    (fp16: holds because every fp32 -> fp16 store goes through Traits<half_t>::from_f, which keeps the compiler from
+    rounding some products once (v_fma_mixlo_f16) and others twice depending on the kernel: gemm_core.hpp.)"""
     from opendcvc_amd import nn
     from opendcvc_amd._lib import DcvcError
     if dtype == torch.float32 and hw[0] > 50:
@@ -151,6 +153,38 @@ def test_chained_blocks_equal_separate_calls(c, hw, dtype):
     other = nn.DepthConvBlock(make_dcb_weights(rng, "m", 64, 64, False), "m", dtype)
     assert not other.can_follow(blocks[1], None) and blocks[2].can_follow(blocks[1], None)
     assert not blocks[2].can_follow(blocks[1], q)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("quant", [False, True])
+@pytest.mark.parametrize("c,hw", [(256, (21, 19)), (128, (9, 33)), (320, (40, 37)), (320, (101, 123))])
+def test_chain_then_conv_equals_separate_calls(c, hw, quant, dtype):
+    """dcb_chain(..., then_conv=conv) (the 1x1 conv after a run of blocks computed in the last block's tail, the run's
+    own result never written: dcvc_dcb_forward_then_conv) = the run followed by the conv kernel, bit for bit, with and
+    without the conv's quant vector; a conv that does not qualify (3x3, other width) takes the separate launch."""
+    from opendcvc_amd import _lib, nn
+    if dtype == torch.float32 and hw[0] > 50:
+        pytest.skip("large map only needed for the fp16 64-pixel kernels")
+    H, W = hw
+    rng = _rng(900 + c + H)
+    blocks = [nn.DepthConvBlock(make_dcb_weights(rng, "m", c, c, False), "m", dtype) for _ in range(2)]
+    csd = {"o.weight": (rng.standard_normal((c, c, 1, 1)) / np.sqrt(c)).astype(np.float32),
+           "o.bias": (rng.standard_normal(c) * 0.1).astype(np.float32)}
+    conv = nn.Conv2d(csd, "o", dtype, epilogue=_lib.EPI_BIAS_QUANT if quant else _lib.EPI_BIAS)
+    assert conv.fusable_after(blocks[-1])
+    x0 = to_dev(rng.standard_normal((H, W, c)).astype(np.float32), blocks[0].cin_p, dtype)
+    q = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)).cuda() if quant else None
+    want = conv(blocks[1](blocks[0](x0)), quant=q)
+    got = nn.dcb_chain(blocks, x0, then_conv=conv, conv_quant=q)
+    buf = torch.full((H, W, 2 * conv.cout_p), 3.0, dtype=dtype, device="cuda")
+    nn.dcb_chain(blocks, x0, then_conv=conv, conv_quant=q, out=buf[:, :, conv.cout_p:])
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert torch.equal(buf[:, :, conv.cout_p:], want) and bool((buf[:, :, :conv.cout_p] == 3.0).all())
+    c3 = {"o.weight": (rng.standard_normal((c, c, 3, 3)) / np.sqrt(9 * c)).astype(np.float32), "o.bias": csd["o.bias"]}
+    conv3 = nn.Conv2d(c3, "o", dtype, pad=1)
+    assert not conv3.fusable_after(blocks[-1])
+    assert torch.equal(nn.dcb_chain(blocks, x0, then_conv=conv3), conv3(blocks[1](blocks[0](x0))))
 
 
 def test_dcb_writes_into_concat_slice():
