@@ -174,6 +174,11 @@ __device__ __forceinline__ void gemm_run(floatx4 (&acc)[MT][NT], const T* X, int
         }
     };
     const int kfull = (kgs / PF) * PF;
+    // The GEMM loops run at raised wave priority: the SIMD's vector issue is arbitrated by priority, then age, so a
+    // co-resident wave in an epilogue / depthwise (VALU) phase otherwise starves this wave's MFMAs, which need only 8 of
+    // every 16 issue cycles and leave the rest to it.  Measured (tools/kbench.py, same box): C=320 136x240 on 8 waves
+    // 95.4 -> 84.0 us, C=256 on 2 x 4 waves 54.0 -> 52.8 us; priority 3 = priority 1.
+    __builtin_amdgcn_s_setprio(1);
     for (int g0 = 0; g0 < kfull; g0 += PF) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) step(g0 + s, s);
@@ -181,6 +186,7 @@ __device__ __forceinline__ void gemm_run(floatx4 (&acc)[MT][NT], const T* X, int
 #pragma unroll
     for (int s = 0; s < PF - 1; ++s)        // remainder groups (kgs % PF), outside the hot loop
         if (kfull + s < kgs) step(kfull + s, s);
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // Implicit-GEMM form for KH x KW convolutions: the reduction runs over (tap, cin) in one uninterrupted
@@ -228,6 +234,7 @@ __device__ __forceinline__ void gemm_taps(floatx4 (&acc)[MT][NT], const T* const
         }
     };
     const int kfull = (kgs / PF) * PF;
+    __builtin_amdgcn_s_setprio(1);   // as in gemm_run
     for (int g0 = 0; g0 < kfull; g0 += PF) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) step(g0 + s, s);
@@ -235,6 +242,7 @@ __device__ __forceinline__ void gemm_taps(floatx4 (&acc)[MT][NT], const T* const
 #pragma unroll
     for (int s = 0; s < PF - 1; ++s)
         if (kfull + s < kgs) step(kfull + s, s);
+    __builtin_amdgcn_s_setprio(0);
 }
 
 template <typename T, int MT, int NT, int PF>

@@ -8,13 +8,14 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-template <int SHAPE>   // 0: 16x16x32, 1: 32x32x16
+template <int SHAPE, int PM = 0, int PV = 0>   // 0: 16x16x32, 1: 32x32x16; wave priorities of the MFMA / VALU waves
 __global__ __launch_bounds__(512, 1) void k(float* out, int n_mfma, int n_valu, int mode)
 {
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float s = 0;
     if (wave < 4) {
         if (mode == 1) return;
+        __builtin_amdgcn_s_setprio(PM);
         half8 a, b;
         for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(threadIdx.x * 0.001f + j); b[j] = (_Float16)(j * 0.01f); }
         if (SHAPE == 0) {
@@ -35,6 +36,7 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int n_mfma, int n_valu, 
         }
     } else {
         if (mode == 0) return;
+        __builtin_amdgcn_s_setprio(PV);
         float u[16];
         for (int j = 0; j < 16; ++j) u[j] = threadIdx.x * 0.01f + j * 0.1f - 3.f;
         for (int it = 0; it < n_valu; ++it)
@@ -149,7 +151,7 @@ void run2(float* out)
     printf("same wave %s, %d %s after every MFMA: %.1f us\n", SHAPE == 0 ? "16x16x32" : "32x32x16", F, TRANS ? "v_exp_f32" : "v_add_f32", ms * 1e3f);
 }
 
-template <int SHAPE>
+template <int SHAPE, int PM = 0, int PV = 0>
 float run(float* out, int nm, int nv, int mode)
 {
     hipEvent_t e0, e1;
@@ -158,7 +160,7 @@ float run(float* out, int nm, int nv, int mode)
     float ms = 0;
     for (int it = 0; it < 2; ++it) {
         hipEventRecord(e0);
-        k<SHAPE><<<256, 512>>>(out, nm, nv, mode);
+        k<SHAPE, PM, PV><<<256, 512>>>(out, nm, nv, mode);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
@@ -178,6 +180,13 @@ int main()
             printf("%s  n_valu=%d: MFMA alone %.1f us, VALU alone %.1f us, both %.1f us (sum %.1f, max %.1f)\n",
                    shape == 0 ? "16x16x32" : "32x32x16", nv, t[0], t[1], t[2], t[0] + t[1], t[0] > t[1] ? t[0] : t[1]);
         }
+    }
+    // the same with wave priorities (s_setprio): MFMA waves raised, then VALU waves raised
+    for (int nv : {1000, 2000}) {
+        printf("16x16x32 n_valu=%d both: prio(mfma,valu) (0,0) %.1f  (1,0) %.1f  (3,0) %.1f  (0,1) %.1f us\n", nv, run<0, 0, 0>(out, nm, nv, 2),
+               run<0, 1, 0>(out, nm, nv, 2), run<0, 3, 0>(out, nm, nv, 2), run<0, 0, 1>(out, nm, nv, 2));
+        printf("32x32x16 n_valu=%d both: prio(mfma,valu) (0,0) %.1f  (1,0) %.1f  (3,0) %.1f  (0,1) %.1f us\n", nv, run<1, 0, 0>(out, nm, nv, 2),
+               run<1, 1, 0>(out, nm, nv, 2), run<1, 3, 0>(out, nm, nv, 2), run<1, 0, 1>(out, nm, nv, 2));
     }
     run2<0, 0, 0>(out);
     run2<0, 1, 0>(out);

@@ -38,7 +38,7 @@ def run(C, H, W, dtype=torch.float16, iters=30):
     print(f"C={C} {H}x{W} {dtype}: head {head.value*1e3:.1f} us  tail {tail.value*1e3:.1f} us  tail {flop/tail.value/1e9:.1f} TFLOP/s  ablate={os.environ.get('DCVC_ABLATE','0')}", flush=True)
 
 if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("conv", "adapt")):
-    shapes = [(256, 136, 240), (256, 68, 120), (384, 68, 120), (128, 17, 30), (320, 136, 240)]
+    shapes = [(256, 136, 240), (256, 68, 120), (384, 68, 120), (128, 17, 30), (320, 136, 240), (384, 136, 240), (512, 68, 120)]
     for C, H, W in shapes if len(sys.argv) < 2 else [tuple(int(v) for v in sys.argv[1:4])]:
         run(C, H, W)
 
