@@ -98,6 +98,11 @@ int dcvc_dcb_forward_then_conv(const dcvc_dcb* h, const void* x0, int64_t ld0, i
  * recorded on that stream around each of its two kernels; returns the mean durations in ms. */
 int dcvc_dcb_profile(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, int H, int W, void* out,
                      int64_t ldo, void* scratch, void* stream, int iters, float* head_ms, float* tail_ms);
+/* The same for the second kernel (dcb_tail_kernel) alone: one head + tail launch, then `iters` back-to-back launches of
+ * the tail between ONE pair of HIP events on `stream` (an event between two kernels costs 3-5 us of dispatch gap that a
+ * per-launch bracket charges to the kernel); returns the mean time per launch in ms.  Blocks without adaptor only. */
+int dcvc_dcb_profile_tail(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, int H, int W, void* out,
+                          int64_t ldo, void* scratch, void* stream, int iters, float* tail_ms);
 
 /* ------------------------------------------------------------------------------------------
  * Dense convolutions (implicit GEMM): 1x1, 3x3 (stride 1 or 2, pad 1), 2x2 stride 2.

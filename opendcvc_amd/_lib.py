@@ -50,6 +50,7 @@ _SIGS = {
     "dcvc_dcb_forward_chained": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _I, _P, _P, _L, _P, _P, _I, _I, _P]),
     "dcvc_dcb_forward_then_conv": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _L]),
     "dcvc_dcb_profile": (_I, [_P, _P, _L, _I, _I, _I, _P, _L, _P, _P, _I, POINTER(c_float), POINTER(c_float)]),
+    "dcvc_dcb_profile_tail": (_I, [_P, _P, _L, _I, _I, _I, _P, _L, _P, _P, _I, POINTER(c_float)]),
     "dcvc_conv_create": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P, _P, POINTER(_P)]),
     "dcvc_conv_destroy": (None, [_P]),
     "dcvc_conv_forward": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _I, _P, _P, _L, _P]),

@@ -1489,6 +1489,33 @@ int dcvc_dcb_profile(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, int
     return rc;
 }
 
+int dcvc_dcb_profile_tail(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0, int H, int W, void* out, int64_t ldo,
+                          void* scratch, void* stream, int iters, float* tail_ms)
+{
+    DCVC_REQUIRE(h && x0 && out && scratch && tail_ms && iters > 0, "dcvc_dcb_profile_tail: bad arguments");
+    DCVC_REQUIRE(c0 == h->cin_p && ld0 >= c0 && ldo >= h->c_p && !h->adapt, "dcvc_dcb_profile_tail: shape mismatch or block with adaptor");
+    SrcPair src{x0, (long)ld0, c0, nullptr, 0, 0};
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    DCVC_HIP(hipEventCreate(&e0));
+    DCVC_HIP(hipEventCreate(&e1));
+    int rc = run_dcb(h, src, H, W, nullptr, out, ldo, scratch, st, nullptr);   // head + tail once: `a` is in the scratch
+    ChainArgs tail_only;
+    tail_only.head_done = 1;
+    if (rc == 0) rc = hipEventRecord(e0, st) == hipSuccess ? 0 : dcvc::E_HIP;
+    for (int i = 0; i < iters && rc == 0; ++i) rc = run_dcb(h, src, H, W, nullptr, out, ldo, scratch, st, nullptr, tail_only);
+    if (rc == 0) {
+        float ms = 0;
+        DCVC_HIP(hipEventRecord(e1, st));
+        DCVC_HIP(hipStreamSynchronize(st));
+        DCVC_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *tail_ms = ms / iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
 int dcvc_conv_create(int dtype, int cin, int cout, int kh, int kw, int stride, int pad, int epilogue,
                      const float* w, const float* b, dcvc_conv** out)
 {

@@ -1,0 +1,54 @@
+"""Developer tool: codes 1 I + N P frames at 1080p (encoder and decoder, sequentially) so that two runs under
+`rocprofv3 --kernel-trace --stats` with different N give the kernel launches per P-frame pair by difference:
+
+    rocprofv3 --kernel-trace --stats --output-format csv -d out4 -- python3 tools/count_launches.py 4
+    rocprofv3 --kernel-trace --stats --output-format csv -d out12 -- python3 tools/count_launches.py 12
+    python3 tools/count_launches.py --diff out4 out12 8
+"""
+import csv, glob, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def calls(root):
+    f = glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursive=True)[0]
+    ours, other = {}, {}
+    for r in csv.DictReader(open(f)):
+        (ours if "_GLOBAL__N_1" in r["Name"] else other)[r["Name"]] = int(r["Calls"])
+    return ours, other
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "--diff":
+    (a, ao), (b, bo), n = calls(sys.argv[2]), calls(sys.argv[3]), int(sys.argv[4])
+    d = {k: (b.get(k, 0) - a.get(k, 0)) / n for k in b}
+    do = {k: (bo.get(k, 0) - ao.get(k, 0)) / n for k in bo}
+    print(f"own kernels per P-frame pair: {sum(d.values()):.1f}; torch / runtime kernels (copies, casts): {sum(do.values()):.1f}")
+    for k, v in sorted(d.items(), key=lambda kv: -kv[1]):
+        if v:
+            print(f"  {v:5.1f}  {k[:100]}")
+    for k, v in sorted(do.items(), key=lambda kv: -kv[1]):
+        if v:
+            print(f"  {v:5.1f}  [other] {k[:100]}")
+    sys.exit(0)
+
+import torch
+import bench
+from opendcvc_amd.pipeline import SequenceDecoder, SequenceEncoder
+torch.set_grad_enabled(False)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+dev = torch.device("cuda", 0)
+(ie, pe), (idec, pdec) = bench.load_models(torch.float16, dev, 1, 0)
+for m in (ie, pe, idec, pdec):
+    m.set_use_two_entropy_coders(True)
+frames = bench.make_frames(0, torch.float16, dev)[1][:n + 1]
+enc = SequenceEncoder(ie, pe, 32, intra_period=64, defer_stream=True)
+dec = SequenceDecoder(idec, pdec, 1080, 1920, True)
+dec.defer = True
+pkts = []
+for x in frames:
+    pkts += enc.encode(x)
+pkts += enc.flush()
+for p in pkts:
+    dec.decode(p)
+dec.flush()
+torch.cuda.synchronize()
+print("coded", len(pkts), "frames")
