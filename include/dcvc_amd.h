@@ -116,6 +116,13 @@ void dcvc_conv_destroy(dcvc_conv* h);
 int dcvc_conv_forward(const dcvc_conv* h, const void* x0, int64_t ld0, int c0, const void* x1,
                       int64_t ld1, int c1, int H, int W, const float* quant, void* out, int64_t ldo,
                       void* stream);
+/* The same with a per-input-channel factor applied while the input tile is staged: conv(x * in_scale[c]), the product
+ * rounded to the element type exactly as dcvc_scale_channels would store it (so the values equal scale_channels followed
+ * by dcvc_conv_forward; in_scale: DEVICE float32 [cin], NULL = plain forward).  Replaces the `ctx_t = conv1(x) * q_feature`
+ * tensor of FeatureExtractor.forward (video_model.py:43-47), whose only reader is temporal_prior_encoder (:238, :311). */
+int dcvc_conv_forward_scaled(const dcvc_conv* h, const void* x0, int64_t ld0, int c0, const void* x1,
+                             int64_t ld1, int c1, int H, int W, const float* in_scale, const float* quant,
+                             void* out, int64_t ldo, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Frame <-> feature layout kernels (dtype = element type of both sides).

@@ -54,6 +54,7 @@ _SIGS = {
     "dcvc_conv_create": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P, _P, POINTER(_P)]),
     "dcvc_conv_destroy": (None, [_P]),
     "dcvc_conv_forward": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _I, _P, _P, _L, _P]),
+    "dcvc_conv_forward_scaled": (_I, [_P, _P, _L, _I, _P, _L, _I, _I, _I, _P, _P, _P, _L, _P]),
     "dcvc_unshuffle8": (_I, [_I, _P, _I, _I, _I, _P, _L, _P]),
     "dcvc_shuffle8_clamp": (_I, [_I, _P, _L, _P, _I, _I, _I, _I, _P, _P]),
     "dcvc_yuv420_to_frame": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

@@ -68,6 +68,19 @@ __device__ __forceinline__ Vec16 load_src(const SrcPair& s, long pix, int c, boo
 
 __device__ __forceinline__ floatx4 load_f4(const float* p) { return *reinterpret_cast<const floatx4*>(p); }
 
+// v[j] * q[c + j] for the kVec channels of a staged input vector, rounded to T like the stand-alone scale_channels kernel
+// (channels beyond qn: unchanged).
+template <typename T>
+__device__ __forceinline__ Vec16 scale_vec(const Vec16& v, const float* __restrict__ q, int c, int qn)
+{
+    constexpr int V = Traits<T>::kVec;
+    float f[V];
+    unpack16<T>(v, f);
+#pragma unroll
+    for (int j = 0; j < V; ++j) f[j] = f[j] * ((c + j) < qn ? q[c + j] : 1.0f);
+    return pack16<T>(f);
+}
+
 // ------------------------------------------------------------------------------------------
 // DepthConvBlock, first kernel:  x -> [x' = adaptor(x)] -> a = wsilu(conv1(x') + b1)
 struct HeadParams {
@@ -659,6 +672,8 @@ struct ConvParams {
     int epi;
     void* out;
     long ldo;
+    const float* in_q;   // optional per-input-channel factor applied while staging (x * in_q[c], rounded to T), in_qn entries
+    int in_qn;
     int halo;      // KH x KW > 1: the input tile + halo is staged once and all taps read it (else: one tap at a time)
     int split_n;   // the passes over the output channels are spread over blockIdx.y (small maps) instead of looped
 };
@@ -691,7 +706,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvParams p)
             const int oy = ty0 + m / TW, ox = tx0 + m % TW;
             const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
             const bool valid = (oy < p.Ho) && (ox < p.Wo) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            lds_store_vec<T>(bufX, ldx, m, c, load_src<T>(p.src, (long)iy * p.W + ix, c, valid));
+            Vec16 v = load_src<T>(p.src, (long)iy * p.W + ix, c, valid);
+            if (p.in_q != nullptr) v = scale_vec<T>(v, p.in_q, c, p.in_qn);
+            lds_store_vec<T>(bufX, ldx, m, c, v);
         }
     };
 
@@ -718,6 +735,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(ConvParams p)
             for (int u = 0; u < U; ++u) {
                 const int it = it0 + u * NTHREADS;
                 const int hp = it / G, c = (it - hp * G) * TR::kVec;
+                if (p.in_q != nullptr) v[u] = scale_vec<T>(v[u], p.in_q, c, p.in_qn);
                 if (it < total) lds_store_vec<T>(bufX, ldx, hp, c, v[u]);
             }
         }
@@ -1563,6 +1581,12 @@ void dcvc_conv_destroy(dcvc_conv* h) { delete h; }
 int dcvc_conv_forward(const dcvc_conv* h, const void* x0, int64_t ld0, int c0, const void* x1, int64_t ld1, int c1,
                       int H, int W, const float* quant, void* out, int64_t ldo, void* stream)
 {
+    return dcvc_conv_forward_scaled(h, x0, ld0, c0, x1, ld1, c1, H, W, nullptr, quant, out, ldo, stream);
+}
+
+int dcvc_conv_forward_scaled(const dcvc_conv* h, const void* x0, int64_t ld0, int c0, const void* x1, int64_t ld1, int c1,
+                             int H, int W, const float* in_scale, const float* quant, void* out, int64_t ldo, void* stream)
+{
     DCVC_REQUIRE(h && x0 && out, "dcvc_conv_forward: null pointer");
     DCVC_REQUIRE(H > 0 && W > 0, "dcvc_conv_forward: empty input %dx%d", H, W);
     DCVC_REQUIRE(c0 % 32 == 0 && c1 % 32 == 0 && c0 + c1 == h->cin_p,
@@ -1589,6 +1613,8 @@ int dcvc_conv_forward(const dcvc_conv* h, const void* x0, int64_t ld0, int c0, c
     cp.w = h->w.p;
     cp.b = (const float*)h->b.p;
     cp.q = quant;
+    cp.in_q = in_scale;
+    cp.in_qn = h->cin;
     cp.epi = h->epi;
     cp.out = out;
     cp.ldo = ldo;

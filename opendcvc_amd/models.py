@@ -486,16 +486,11 @@ class DMC(CompressionModel):
     def _fe_input(self, variant, ref_buf):
         return ref_buf if variant == "p" else self._unshuffle8(ref_buf)
 
-    def _extractor_part1(self, variant, ref_buf, q_feature):
-        x1 = L.dcb_chain(self._fe1(variant), self._fe_input(variant, ref_buf))
-        return x1, self._scaled_context(x1, q_feature)
-
-    def _scaled_context(self, x1, q_feature):
-        ctx_t = torch.empty_like(x1)
-        H, W, C, ld = L._geom(x1)
-        check(_lib.lib().dcvc_scale_channels(L.dtype_code(x1.dtype), L._p(x1), ld, L._p(q_feature), H * W, C,
-                                             L._p(ctx_t), C, self._stream()), "scale_channels")
-        return ctx_t
+    def _extractor_part1(self, variant, ref_buf):
+        """conv1 of the feature extractor.  The reference's second output ctx_t = x1 * q_feature (video_model.py:43-47) is
+        read by temporal_prior_encoder only: its first conv scales x1 while staging it (_prior_params), the tensor is
+        never materialised."""
+        return L.dcb_chain(self._fe1(variant), self._fe_input(variant, ref_buf))
 
     def _extractor_part2(self, x1):
         return L.dcb_chain(self._layers["fe2"], x1)
@@ -508,8 +503,9 @@ class DMC(CompressionModel):
         outs = L.dcb_chain(blocks + self._layers["fe2"], self._fe_input(variant, ref_buf), return_all=True)
         return outs[len(blocks) - 1], outs[-1]
 
-    def _prior_params(self, z_hat, ctx_t, yh, yw):
-        """res_prior_param_decoder (video_model.py:279-286) -> [yh, yw, 384] = q_dec | scales | means"""
+    def _prior_params(self, z_hat, x1, q_feature, yh, yw):
+        """res_prior_param_decoder (video_model.py:279-286) -> [yh, yw, 384] = q_dec | scales | means.
+        x1, q_feature: temporal_prior_encoder reads ctx_t = x1 * q_feature (same values as the stand-alone product)"""
         n = self._layers
         cat = torch.empty((yh, yw, 3 * arch.DMC_CH_Y), dtype=z_hat.dtype, device=z_hat.device)
         h = n["hyper_dec"][1](n["hyper_dec"][0](z_hat))
@@ -517,7 +513,7 @@ class DMC(CompressionModel):
             n["hyper_dec"][2](h, out=cat[:, :, :arch.DMC_CH_Y])
         else:
             self._crop(n["hyper_dec"][2](h), yh, yw, out=cat[:, :, :arch.DMC_CH_Y])
-        n["temporal"](ctx_t, out=cat[:, :, arch.DMC_CH_Y:])
+        n["temporal"](x1, in_scale=q_feature, out=cat[:, :, arch.DMC_CH_Y:])
         return L.dcb_chain(n["fusion"], cat, then_conv=n["fusion_out"])          # (the last conv runs in the last tail)
 
     def _spatial_prior(self, y_hat, params):
@@ -629,16 +625,14 @@ class DMC(CompressionModel):
         def front():
             if ahead is not None:
                 x1, ctx = ahead[2], ahead[3]
-                ctx_t = self._scaled_context(x1, q["q_feature"])
             else:
                 x1, ctx = self._extractor_both(variant, ref_buf)
-                ctx_t = self._scaled_context(x1, q["q_feature"])
             e = L.dcb_chain(n["enc_conv2"] + [n["enc_conv3"]], n["enc_conv1"](xin), ctx, quant=q["q_encoder"])
             y = n["enc_down"](e)
             yh, yw = y.shape[0], y.shape[1]
             z = n["hyper_enc"][2](n["hyper_enc"][1](n["hyper_enc"][0](self._pad_for_y(y))))
             z_hat, z8 = self._quantize_z(z)
-            params = self._prior_params(z_hat, ctx_t, yh, yw)
+            params = self._prior_params(z_hat, x1, q["q_feature"], yh, yw)
             nsym = (C // 2) * yh * yw
             y_hat = torch.empty((yh, yw, C), dtype=dtype, device=device)
             packed = torch.empty((2, nsym), dtype=torch.int16, device=device)
@@ -710,13 +704,12 @@ class DMC(CompressionModel):
         n_half = (C // 2) * yh * yw
         zb = ec.pinned("z_dec", nz)
 
-        x1, ctx_t = self._graphs.run(("dec_0",) + key,
-                                     lambda: self._extractor_part1(variant, ref_buf, q["q_feature"]))
+        x1 = self._graphs.run(("dec_0",) + key, lambda: self._extractor_part1(variant, ref_buf))
         ec.get_decoded(zb.view(np.int8, nz))
 
         def after_z():
             z_hat = self._z_to_device(zb.view(np.int8, nz), zh, zw, dtype, device)
-            params = self._prior_params(z_hat, ctx_t, yh, yw)
+            params = self._prior_params(z_hat, x1, q["q_feature"], yh, yw)
             y_hat = torch.empty((yh, yw, C), dtype=dtype, device=device)
             return params, y_hat, self._index_to_host(2, 0, params[:, :, C:2 * C], yh, yw, C, "p0")
 

@@ -223,20 +223,24 @@ class Conv2d:
             return 2 * Ho, 2 * Wo
         return Ho, Wo
 
-    def __call__(self, x0, x1=None, quant=None, out=None):
+    def __call__(self, x0, x1=None, quant=None, out=None, in_scale=None):
+        """in_scale: float32 device vector [cin]: the conv of x * in_scale[c] (the product rounded to the element type,
+        = scale_channels followed by the conv, without the intermediate tensor)"""
         L = _lib.lib()
         H, W, c0, ld0 = _geom(x0)
         c1, ld1 = 0, 0
         if x1 is not None:
             _, _, c1, ld1 = _geom(x1)
+        if in_scale is not None and (in_scale.dtype != torch.float32 or in_scale.numel() < self.cin):
+            raise DcvcError(f"in_scale must be a float32 vector of at least {self.cin} entries")
         Ho, Wo = self.out_hw(H, W)
         if out is None:
             out = torch.empty((Ho, Wo, self.cout_p), dtype=self.dtype, device=x0.device)
         H2, W2, co, ldo = _geom(out)
         if (H2, W2) != (Ho, Wo) or co < self.cout_p:
             raise DcvcError(f"output view {tuple(out.shape)} does not fit conv output {(Ho, Wo, self.cout_p)}")
-        check(L.dcvc_conv_forward(self.h, _p(x0), ld0, c0, _p(x1), ld1, c1, H, W, _p(quant), _p(out), ldo,
-                                  _stream()), "dcvc_conv_forward")
+        check(L.dcvc_conv_forward_scaled(self.h, _p(x0), ld0, c0, _p(x1), ld1, c1, H, W, _p(in_scale), _p(quant), _p(out),
+                                         ldo, _stream()), "dcvc_conv_forward")
         return out
 
 
@@ -258,8 +262,8 @@ class ResidualBlockWithStride2:
         self.down = Conv2d(sd, prefix + ".down", dtype, 2, 0)
         self.conv = DepthConvBlock(sd, prefix + ".conv", dtype, shortcut=True)
 
-    def __call__(self, x, out=None):
-        return self.conv(self.down(x), out=out)
+    def __call__(self, x, out=None, in_scale=None):
+        return self.conv(self.down(x, in_scale=in_scale), out=out)
 
 
 class ResidualBlockUpsample:

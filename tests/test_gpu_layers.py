@@ -253,6 +253,32 @@ def test_conv(case, dtype):
     compare(got[:, :, :c_log], ref, dtype, f"conv {case}")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("geom", [(256, 256, 2, 2, 0, 14, 22), (256, 128, 3, 1, 1, 9, 11), (320, 192, 1, 1, 0, 7, 9), (256, 128, 3, 2, 1, 12, 18)])
+def test_conv_with_input_scale_equals_scale_then_conv(geom, dtype):
+    """Conv2d(x, in_scale=q) (the per-channel factor applied while the input tile is staged: temporal_prior_encoder reading
+    ctx_t = x1 * q_feature) = dcvc_scale_channels followed by the plain conv, bit for bit - all staging forms (one tap at
+    a time, halo tile, 1x1)."""
+    import ctypes
+    from opendcvc_amd import _lib, nn
+    cin, cout, k, stride, pad, H, W = geom
+    rng = _rng(700 + cin + k + stride)
+    sd = {"m.weight": (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32),
+          "m.bias": (rng.standard_normal(cout) * 0.1).astype(np.float32)}
+    conv = nn.Conv2d(sd, "m", dtype, stride, pad)
+    x = to_dev(rng.standard_normal((H, W, cin)).astype(np.float32), conv.cin_p, dtype)
+    q = torch.from_numpy(rng.uniform(0.5, 1.5, cin).astype(np.float32)).cuda()
+    xs = torch.empty_like(x)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.lib().dcvc_scale_channels(nn.dtype_code(dtype), nn._p(x), conv.cin_p, nn._p(q), H * W, conv.cin_p,
+                                              nn._p(xs), conv.cin_p, st), "scale_channels")
+    want = conv(xs)
+    got = conv(x, in_scale=q)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert not torch.equal(got, conv(x))          # (the factor is really applied)
+
+
 def test_conv_concat_sources():
     from opendcvc_amd import nn
     rng = _rng(9)

@@ -13,4 +13,8 @@ rm -rf $O/prof_roof $O/prof_bench
 python3 bench.py --frame 3840x2160 --no-cpu-baseline > $O/r02_bench_4k.json 2>> $O/bench.err
 python3 tools/iframe_time.py > $O/r02_iframe_time.txt 2>> $O/bench.err
 python3 tools/kbench.py > $O/r02_kbench.txt 2>> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/cl4 -- python3 tools/count_launches.py 4 > /dev/null 2>> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/cl12 -- python3 tools/count_launches.py 12 > /dev/null 2>> $O/bench.err
+python3 tools/count_launches.py --diff $O/cl4 $O/cl12 8 > $O/r02_launches_per_pair.txt
+rm -rf $O/cl4 $O/cl12
 echo done
