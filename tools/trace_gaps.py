@@ -43,5 +43,46 @@ def main(root):
         print("   short-gap histogram (us: count): " + " ".join(f"{k}:{v}" for k, v in sorted(hist.items())))
 
 
+def union(root, lo_frac=0.0, hi_frac=1.0):
+    """All queues together: fraction of the wall time during which at least one kernel runs, over the densest part of
+    the trace (the longest stretch without an idle period > 20 ms = the bench's timed pipeline window)."""
+    files = glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)
+    iv = []
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            iv.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    iv.sort()
+    # split into stretches separated by > 20 ms of nothing
+    stretches, cur, end = [], [], None
+    for s_, e_ in iv:
+        if end is not None and s_ - end > 20_000_000:
+            stretches.append(cur)
+            cur = []
+        cur.append((s_, e_))
+        end = e_ if end is None else max(end, e_)
+    stretches.append(cur)
+    for st in sorted(stretches, key=lambda c: -(max(e for _, e in c) - c[0][0]))[:3]:
+        t0, t1 = st[0][0], max(e for _, e in st)
+        busy, idle_hist, last = 0, defaultdict(int), st[0][0]
+        idle_total = 0
+        cur_s, cur_e = st[0]
+        for s_, e_ in st[1:]:
+            if s_ > cur_e:
+                busy += cur_e - cur_s
+                g = s_ - cur_e
+                idle_total += g
+                idle_hist[min(g // 10_000, 50)] += g
+                cur_s, cur_e = s_, e_
+            else:
+                cur_e = max(cur_e, e_)
+        busy += cur_e - cur_s
+        span = t1 - t0
+        print(f"stretch of {span/1e6:.1f} ms, {len(st)} kernels: some kernel running {100*busy/span:.1f} % of the time, idle {idle_total/1e6:.1f} ms")
+        print("   idle time by gap length (x10 us: ms): " + " ".join(f"{k}:{v/1e6:.1f}" for k, v in sorted(idle_hist.items())))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "--union":
+        union(sys.argv[1])
+        sys.exit(0)
     main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/trace")
