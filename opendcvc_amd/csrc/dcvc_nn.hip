@@ -227,6 +227,12 @@ struct TailParams {
     int nplain;
     const float* nq;
     int n_log;
+    // HEADIN kernels (small maps, block without adaptor, one source): the block's own first conv + activation is
+    // computed here on the tile + halo (hx = the block's input) instead of by dcb_head_kernel; `a` is then unused
+    const void* hx;
+    long ldhx;
+    const void* hw1;
+    const float* hb1;
     int ablate;          // debug: bit0 skip dw, bit1 skip GEMM2, bit2 skip FFN GEMM3, bit3 skip FFN GEMM4
     unsigned long long* stamps;   // diagnostic build only (DCVC_STAMPS): 8 cycle counters per workgroup
 };
@@ -270,15 +276,24 @@ struct TailLds {
     static constexpr int M = Tile<MT>::M;
     static constexpr int VC = NW * NTV * 16;
     static constexpr int HALO = (Tile<MT>::TH + 2) * (Tile<MT>::TW + 2);
+    static constexpr int HPASS = (HALO + M - 1) / M;      // HEADIN: the halo tile as HPASS GEMM passes of M rows
     static constexpr int lds_slab = dw_slab_max<T>() + TR::kPad;
     static constexpr int ldv = VC + TR::kPad;
     static constexpr size_t v_elems = (size_t)M * ldv > (size_t)HALO * lds_slab ? (size_t)M * ldv : (size_t)HALO * lds_slab;
-    static size_t bytes(int C) { return ((size_t)M * (C + TR::kPad) + v_elems) * sizeof(T); }
+    static size_t bytes(int C, bool headin = false)
+    {
+        const size_t halo_elems = (size_t)HPASS * M * (C + TR::kPad);    // x, then a, on the tile + halo (aliases bufV)
+        return ((size_t)M * (C + TR::kPad) + (headin && halo_elems > v_elems ? halo_elems : v_elems)) * sizeof(T);
+    }
 };
 
 // RAG ("ragged"): the width is 4 channel tiles short of NTW * NW * 16 (C = 320 on 8 waves x 3 tiles): the
 // waves whose last tile does not exist run it on a clamped weight tile and drop the result.
-template <typename T, int MT, int NTW, int NW, bool RAG = false>
+// HEADIN (32-pixel tiles, blocks without adaptor): the block's first conv + activation a = gate(W1 x + b1) is computed
+// here on the tile and its 1-pixel halo (60 of 64 GEMM rows for a 4 x 8 tile) instead of by dcb_head_kernel - same k
+// order, same epilogue, same fp16 rounding, so the same `a`; pixels outside the picture get a = 0 (the depthwise conv's
+// zero padding).  One launch and one activation round trip less for the small-map blocks that follow a conv.
+template <typename T, int MT, int NTW, int NW, bool RAG = false, bool HEADIN = false>
 __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) void dcb_tail_kernel(TailParams p)
 {
     using TR = Traits<T>;
@@ -315,44 +330,96 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
     }
     auto tile_exists = [&](int i) { return !RAG || tiles[i] < C / 16; };
     WPre<T, NTW, PF> pre2;   // W2's first groups are requested now and land during the depthwise stage
-    gemm_prefetch<T, NTW, PF>(pre2, C / KG, reinterpret_cast<const frag_t*>(p.w2), C / KG, 0, wtiles, lane);
+    if constexpr (!HEADIN)   // (HEADIN: after the head GEMM, whose own weight ring needs the registers)
+        gemm_prefetch<T, NTW, PF>(pre2, C / KG, reinterpret_cast<const frag_t*>(p.w2), C / KG, 0, wtiles, lane);
+
+    if constexpr (HEADIN) {
+        // x on the tile + halo -> bufV (rows = halo pixels in (y, x) order, zero beyond the picture / the halo)
+        constexpr int HW_ = TW + 2, HALO = LD::HALO, HROWS = LD::HPASS * M;
+        const T* hx = reinterpret_cast<const T*>(p.hx);
+        for (int it = tid; it < HROWS * GC; it += NTHREADS_) {
+            const int hp = it / GC, c = (it - hp * GC) * V;
+            const int y = ty0 - 1 + hp / HW_, x = tx0 - 1 + hp % HW_;
+            Vec16 v = VEC16_ZERO;
+            if (hp < HALO && y >= 0 && y < p.H && x >= 0 && x < p.W)
+                v = *reinterpret_cast<const Vec16*>(hx + ((long)y * p.W + x) * p.ldhx + c);
+            lds_store_vec<T>(bufV, ldx, hp, c, v);
+        }
+        __syncthreads();
+        floatx4 hacc[LD::HPASS][MT][NTW];
+#pragma unroll
+        for (int ps = 0; ps < LD::HPASS; ++ps) {
+            zero_acc(hacc[ps]);
+            gemm_acc<T, MT, NTW, PF>(hacc[ps], bufV + ps * M * ldx, ldx, C / KG, reinterpret_cast<const frag_t*>(p.hw1), C / KG, 0,
+                                     wtiles, lane);
+        }
+        __syncthreads();   // every wave has finished reading x: a replaces it in place
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const int ch0 = tiles[i] * 16 + cq;
+            const floatx4 bias = load_f4(p.hb1 + wtiles[i] * 16 + cq);
+            if (tile_exists(i)) {
+#pragma unroll
+                for (int ps = 0; ps < LD::HPASS; ++ps)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const int hp = ps * M + m * 16 + pl;
+                        const int y = ty0 - 1 + hp / HW_, x = tx0 - 1 + hp % HW_;
+                        const bool inside = hp < HALO && y >= 0 && y < p.H && x >= 0 && x < p.W;
+                        floatx4 v = hacc[ps][m][i] + bias;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = inside ? TR::gate(v[r]) : 0.f;
+                        lds_store_quad<T>(bufV, ldx, hp, ch0, v);
+                    }
+            }
+        }
+        gemm_prefetch<T, NTW, PF>(pre2, C / KG, reinterpret_cast<const frag_t*>(p.w2), C / KG, 0, wtiles, lane);
+        __syncthreads();
+    }
 
     {   // depthwise 3x3 (zero padding), taps in (ky,kx) order, + bias.  The activation tile and its
         // 1-pixel halo go through LDS one 64-channel slab at a time (each input element is fetched
         // from L2 1.4-1.6x instead of 9x); the next slab is prefetched into registers meanwhile.
+        // (HEADIN: the whole halo tile of `a` is in bufV already, rows ldx apart.)
         constexpr int DW_SLAB = (!RAG && dw_slab_max<T>() == 128 && (NTW * NW) % 8 == 0) ? 128 : 64;
         constexpr int HW_ = TW + 2, HALO = LD::HALO, GS = DW_SLAB / V, lds_s = LD::lds_slab;
         constexpr int NLD = (HALO * GS + NTHREADS_ - 1) / NTHREADS_;
         const T* wd = reinterpret_cast<const T*>(p.wd);
         const int nslab = C / DW_SLAB;
-        Vec16 pre[NLD];
+        const int tap_ld = HEADIN ? ldx : lds_s;       // row stride of the tap source
+        Vec16 pre[HEADIN ? 1 : NLD];
         auto fetch = [&](int slab) {
+            if constexpr (!HEADIN) {
 #pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int it = tid + k * NTHREADS_;
-                Vec16 v = VEC16_ZERO;
-                if (it < HALO * GS) {
-                    const int hp = it / GS, c = slab * DW_SLAB + (it - hp * GS) * V;
-                    const int y = ty0 - 1 + hp / HW_, x = tx0 - 1 + hp % HW_;
-                    if (y >= 0 && y < p.H && x >= 0 && x < p.W && !ABLATED(1))
-                        v = *reinterpret_cast<const Vec16*>(a + ((long)y * p.W + x) * p.lda + c);
+                for (int k = 0; k < NLD; ++k) {
+                    const int it = tid + k * NTHREADS_;
+                    Vec16 v = VEC16_ZERO;
+                    if (it < HALO * GS) {
+                        const int hp = it / GS, c = slab * DW_SLAB + (it - hp * GS) * V;
+                        const int y = ty0 - 1 + hp / HW_, x = tx0 - 1 + hp % HW_;
+                        if (y >= 0 && y < p.H && x >= 0 && x < p.W && !ABLATED(1))
+                            v = *reinterpret_cast<const Vec16*>(a + ((long)y * p.W + x) * p.lda + c);
+                    }
+                    pre[k] = v;
                 }
-                pre[k] = v;
             }
         };
         fetch(0);
         for (int slab = 0; slab < nslab; ++slab) {
+            if constexpr (!HEADIN) {
 #pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int it = tid + k * NTHREADS_;
-                if (it < HALO * GS) {
-                    const int hp = it / GS, cs = (it - hp * GS) * V;
-                    *reinterpret_cast<Vec16*>(bufV + hp * lds_s + cs) = pre[k];   // natural order inside the slab
+                for (int k = 0; k < NLD; ++k) {
+                    const int it = tid + k * NTHREADS_;
+                    if (it < HALO * GS) {
+                        const int hp = it / GS, cs = (it - hp * GS) * V;
+                        *reinterpret_cast<Vec16*>(bufV + hp * lds_s + cs) = pre[k];   // natural order inside the slab
+                    }
                 }
             }
             // a thread always works on the same channel group of a slab (NTHREADS_ % GS == 0): its 9 tap
             // weights and the bias are fetched once per slab, before the barrier
             const int cs = (tid % GS) * V, c = slab * DW_SLAB + cs;
+            const int tap_c = HEADIN ? c : cs;          // channel offset inside a tap source row
             Vec16 wtap[9];
 #pragma unroll
             for (int t = 0; t < 9; ++t) wtap[t] = *reinterpret_cast<const Vec16*>(wd + t * C + c);
@@ -375,7 +442,7 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx)
-                        v[ky * 3 + kx] = *reinterpret_cast<const Vec16*>(bufV + ((my + ky) * HW_ + mx + kx) * lds_s + cs);
+                        v[ky * 3 + kx] = *reinterpret_cast<const Vec16*>(bufV + ((my + ky) * HW_ + mx + kx) * tap_ld + tap_c);
             };
             auto taps_apply = [&](int m, const Vec16 (&v)[9]) {
                 float s[V];
@@ -911,13 +978,13 @@ size_t tail_lds(int c)
     return TailLds<T, MT, TailCfg<MT, NTW, NW>::NTV, NW>::bytes(c);
 }
 
-template <typename T, int MT, int NTW, int NW, bool RAG = false>
+template <typename T, int MT, int NTW, int NW, bool RAG = false, bool HEADIN = false>
 int launch_tail(const TailParams& tp, int grid, int C, hipStream_t st)
 {
-    const size_t lds = tail_lds<T, MT, NTW, NW>(C);
-    int rc = set_lds(dcb_tail_kernel<T, MT, NTW, NW, RAG>, lds);
+    const size_t lds = TailLds<T, MT, TailCfg<MT, NTW, NW>::NTV, NW>::bytes(C, HEADIN);
+    int rc = set_lds(dcb_tail_kernel<T, MT, NTW, NW, RAG, HEADIN>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((dcb_tail_kernel<T, MT, NTW, NW, RAG>), dim3(grid), dim3(NW * 64), lds, st, tp);
+    hipLaunchKernelGGL((dcb_tail_kernel<T, MT, NTW, NW, RAG, HEADIN>), dim3(grid), dim3(NW * 64), lds, st, tp);
     return 0;
 }
 
@@ -1043,9 +1110,13 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     hp.a_out = a_buf;
     hp.lda = C;
     const int kin = src.c0 + src.c1;
+    // Small maps (32-pixel tiles, 4-wave tails), block without adaptor, one source: no head launch - the tail computes
+    // `a` on its tile + halo itself (dcb_tail_kernel<..., HEADIN>)
+    constexpr bool kHeadInKernel = sizeof(T) == 2 && MT == 2 && NTW <= 4;
+    const bool head_in = kHeadInKernel && !ch.head_done && !h->adapt && src.c1 == 0;
     if (ev) DCVC_HIP(hipEventRecord(ev[0], st));
-    if (ch.head_done) {
-        // `a` was written by the previous block's tail
+    if (ch.head_done || head_in) {
+        // `a` was written by the previous block's tail / is computed by this block's tail
     } else if (h->adapt) {
         // two sources: one at a time through LDS (half the staging buffer: a 64-pixel tile of 256 + 256 channels then
         // leaves room for two workgroups per CU, i.e. half the weight fragments per pixel of the 32-pixel form)
@@ -1095,6 +1166,12 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     tp.q = quant;
     tp.out = out;
     tp.ldo = ldo;
+    if (head_in) {
+        tp.hx = src.x0;
+        tp.ldhx = src.ld0;
+        tp.hw1 = h->w1.p;
+        tp.hb1 = (const float*)h->b1.p;
+    }
     if (ch.next) {
         tp.nw1 = ch.next->w1.p;
         tp.nb1 = (const float*)ch.next->b1.p;
@@ -1167,7 +1244,9 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
             rc = launch_tail<T, MT, NTW / 2, 8>(tp, grid, C, st);
         else if constexpr (NTW == 5 && sizeof(T) == 2)
             rc = launch_tail<T, MT, 3, 8, true>(tp, grid, C, st);   // 20 tiles on 8 waves: 4 waves x 3 + 4 waves x 2
-        else
+        else if constexpr (kHeadInKernel) {
+            rc = head_in ? launch_tail<T, MT, NTW, 4, false, true>(tp, grid, C, st) : launch_tail<T, MT, NTW, 4>(tp, grid, C, st);
+        } else
             rc = launch_tail<T, MT, NTW, 4>(tp, grid, C, st);
         if (rc) return rc;
     }
