@@ -1112,7 +1112,7 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     const int kin = src.c0 + src.c1;
     // Small maps (32-pixel tiles, 4-wave tails), block without adaptor, one source: no head launch - the tail computes
     // `a` on its tile + halo itself (dcb_tail_kernel<..., HEADIN>)
-    constexpr bool kHeadInKernel = sizeof(T) == 2 && MT == 2 && NTW <= 4;
+    constexpr bool kHeadInKernel = sizeof(T) == 2 && MT == 2 && (NTW <= 4 || NTW == 6);   // (6: the 8-wave tail of C=384)
     const bool head_in = kHeadInKernel && !ch.head_done && !h->adapt && src.c1 == 0;
     if (ev) DCVC_HIP(hipEventRecord(ev[0], st));
     if (ch.head_done || head_in) {
@@ -1240,11 +1240,13 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         // workgroups per CU do that job better (8 waves there measured 116 us vs 63 us; 128-pixel tiles on 8 waves,
         // MT = 8 x NTW = 2, spill at 256 VGPRs and measured 66 us against 59 us for the same build).
         int rc;
-        if constexpr (NTW >= 6 && NTW % 2 == 0 && sizeof(T) == 2)
+        if constexpr (NTW == 6 && kHeadInKernel)
+            rc = head_in ? launch_tail<T, MT, 3, 8, false, true>(tp, grid, C, st) : launch_tail<T, MT, 3, 8>(tp, grid, C, st);
+        else if constexpr (NTW >= 6 && NTW % 2 == 0 && sizeof(T) == 2)
             rc = launch_tail<T, MT, NTW / 2, 8>(tp, grid, C, st);
         else if constexpr (NTW == 5 && sizeof(T) == 2)
             rc = launch_tail<T, MT, 3, 8, true>(tp, grid, C, st);   // 20 tiles on 8 waves: 4 waves x 3 + 4 waves x 2
-        else if constexpr (kHeadInKernel) {
+        else if constexpr (kHeadInKernel && NTW <= 4) {
             rc = head_in ? launch_tail<T, MT, NTW, 4, false, true>(tp, grid, C, st) : launch_tail<T, MT, NTW, 4>(tp, grid, C, st);
         } else
             rc = launch_tail<T, MT, NTW, 4>(tp, grid, C, st);
