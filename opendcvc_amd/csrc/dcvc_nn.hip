@@ -1077,6 +1077,7 @@ static bool use_ps(const dcvc_dcb* h, int H, int W)
 // block's tail produced it); if next != NULL this block's tail also produces next's `a` in the other slot
 struct ChainArgs {
     int head_done = 0, a_slot = 0;
+    int separate_head = 0;      // measurement aid: never fold the head into the tail (so that `a` exists in the scratch)
     const dcvc_dcb* next = nullptr;
     // or: a 1x1 conv of the same width fused behind the block (its output replaces the block's)
     const dcvc_conv* conv = nullptr;
@@ -1113,7 +1114,7 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     // Small maps (32-pixel tiles, 4-wave tails), block without adaptor, one source: no head launch - the tail computes
     // `a` on its tile + halo itself (dcb_tail_kernel<..., HEADIN>)
     constexpr bool kHeadInKernel = sizeof(T) == 2 && MT == 2 && (NTW <= 4 || NTW == 6);   // (6: the 8-wave tail of C=384)
-    const bool head_in = kHeadInKernel && !ch.head_done && !h->adapt && src.c1 == 0;
+    const bool head_in = kHeadInKernel && !ch.head_done && !ch.separate_head && !h->adapt && src.c1 == 0;
     if (ev) DCVC_HIP(hipEventRecord(ev[0], st));
     if (ch.head_done || head_in) {
         // `a` was written by the previous block's tail / is computed by this block's tail
@@ -1598,7 +1599,9 @@ int dcvc_dcb_profile_tail(const dcvc_dcb* h, const void* x0, int64_t ld0, int c0
     hipEvent_t e0, e1;
     DCVC_HIP(hipEventCreate(&e0));
     DCVC_HIP(hipEventCreate(&e1));
-    int rc = run_dcb(h, src, H, W, nullptr, out, ldo, scratch, st, nullptr);   // head + tail once: `a` is in the scratch
+    ChainArgs first;
+    first.separate_head = 1;
+    int rc = run_dcb(h, src, H, W, nullptr, out, ldo, scratch, st, nullptr, first);   // head + tail once: `a` is in the scratch
     ChainArgs tail_only;
     tail_only.head_done = 1;
     if (rc == 0) rc = hipEventRecord(e0, st) == hipSuccess ? 0 : dcvc::E_HIP;
