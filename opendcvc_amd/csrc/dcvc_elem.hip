@@ -335,7 +335,7 @@ __global__ __launch_bounds__(EB) void prior_enc_kernel(PriorEncArgs a)
         const int pl = it / Cg, cc = it - pl * Cg;
         const int64_t p = p0 + pl;
         if (p >= HW) continue;
-        const int h = (int)(p / a.W), w = (int)(p - (int64_t)h * a.W);
+        const int h = (int)p / a.W, w = (int)p - h * a.W;      // (H * W < 2^31: 32-bit division)
         const int ga = active_group(a.n_groups, a.step, h, w);
         int16_t packed = 0;
         for (int g = 0; g < a.n_groups; ++g) {
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(EB) void prior_dec_index_kernel(int n_groups, int s
         const int pl = it / Cg, cc = it - pl * Cg;
         const int64_t p = p0 + pl;
         if (p >= HW) continue;
-        const int h = (int)(p / W), w = (int)(p - (int64_t)h * W);
+        const int h = (int)p / W, w = (int)p - h * W;
         const int ch = cc + active_group(n_groups, step, h, w) * Cg;
         const float scl = clampf(ld(sc, p * lds + ch), kScaleMin, kScaleMax);
         const bool keep = thres < 0.f || scl > thres;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(EB) void prior_dec_restore_kernel(int n_groups, int
         const int pl = it / Cg, cc = it - pl * Cg;
         const int64_t p = p0 + pl;
         if (p >= HW) continue;
-        const int h = (int)(p / W), w = (int)(p - (int64_t)h * W);
+        const int h = (int)p / W, w = (int)p - h * W;
         const int ga = active_group(n_groups, step, h, w);
         for (int g = 0; g < n_groups; ++g) {
             const int ch = cc + g * Cg;
@@ -444,8 +444,8 @@ __global__ void prior_finish_kernel(int q_mode, T* yh, int64_t ldh, const T* qs,
 {
     const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
     if (i >= HW * C) return;
-    const int c = (int)(i % C);
-    const int64_t p = i / C;
+    const int64_t p = (int)i / C;           // (H * W * C < 2^31, checked by the caller: 32-bit division)
+    const int c = (int)i - (int)p * C;
     float q;
     if (q_mode == 0) {
         q = ld(qs, p * ldq + c);
@@ -729,6 +729,7 @@ int dcvc_prior_enc_step(int dtype, int n_groups, int step, int q_mode, const voi
                         void* stream)
 {
     DCVC_REQUIRE(y && qsrc && scales && means && yhat_out && packed_chw, "dcvc_prior_enc_step: null pointer");
+    DCVC_REQUIRE((int64_t)H * W < (1ll << 31), "dcvc_prior_enc_step: map too large");
     DCVC_REQUIRE((n_groups == 2 || n_groups == 4) && step >= 0 && step < n_groups && C % n_groups == 0,
                  "dcvc_prior_enc_step: bad groups/step %d/%d", n_groups, step);
     DCVC_REQUIRE(step == 0 || yhat_in, "dcvc_prior_enc_step: yhat_in required after step 0");
@@ -747,6 +748,7 @@ int dcvc_prior_dec_index(int dtype, int n_groups, int step, const void* scales, 
                          float thres, uint8_t* idx_chw, void* stream)
 {
     DCVC_REQUIRE(scales && idx_chw, "dcvc_prior_dec_index: null pointer");
+    DCVC_REQUIRE((int64_t)H * W < (1ll << 31), "dcvc_prior_dec_index: map too large");
     DCVC_REQUIRE((n_groups == 2 || n_groups == 4) && step >= 0 && step < n_groups && C % n_groups == 0,
                  "dcvc_prior_dec_index: bad groups/step");
     const int grid = (int)(((int64_t)H * W + PT - 1) / PT);
@@ -762,6 +764,7 @@ int dcvc_prior_dec_restore(int dtype, int n_groups, int step, const int8_t* sym_
                            int W, int C, const void* yhat_in, int64_t ldhi, void* yhat_out, int64_t ldho, void* stream)
 {
     DCVC_REQUIRE(sym_chw && means && yhat_out, "dcvc_prior_dec_restore: null pointer");
+    DCVC_REQUIRE((int64_t)H * W < (1ll << 31), "dcvc_prior_dec_restore: map too large");
     DCVC_REQUIRE((n_groups == 2 || n_groups == 4) && step >= 0 && step < n_groups && C % n_groups == 0,
                  "dcvc_prior_dec_restore: bad groups/step");
     DCVC_REQUIRE(step == 0 || yhat_in, "dcvc_prior_dec_restore: yhat_in required after step 0");
@@ -779,6 +782,7 @@ int dcvc_prior_finish(int dtype, int q_mode, void* yhat, int64_t ldh, const void
                       void* stream)
 {
     DCVC_REQUIRE(yhat && qsrc, "dcvc_prior_finish: null pointer");
+    DCVC_REQUIRE((int64_t)H * W * C < (1ll << 31), "dcvc_prior_finish: latent too large");
     return typed(dtype, [&](auto tag) {
         using T = decltype(tag);
         prior_finish_kernel<T><<<nblocks((int64_t)H * W * C), EB, 0, (hipStream_t)stream>>>(q_mode, (T*)yhat, ldh, (const T*)qsrc, ldq,
