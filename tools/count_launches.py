@@ -9,11 +9,15 @@ import csv, glob, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+TIMES = {}
+
+
 def calls(root):
     f = glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursive=True)[0]
     ours, other = {}, {}
     for r in csv.DictReader(open(f)):
         (ours if "_GLOBAL__N_1" in r["Name"] else other)[r["Name"]] = int(r["Calls"])
+        TIMES[(root, r["Name"])] = float(r["TotalDurationNs"])
     return ours, other
 
 
@@ -22,12 +26,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "--diff":
     d = {k: (b.get(k, 0) - a.get(k, 0)) / n for k in b}
     do = {k: (bo.get(k, 0) - ao.get(k, 0)) / n for k in bo}
     print(f"own kernels per P-frame pair: {sum(d.values()):.1f}; torch / runtime kernels (copies, casts): {sum(do.values()):.1f}")
-    for k, v in sorted(d.items(), key=lambda kv: -kv[1]):
+    us = lambda k: (TIMES.get((sys.argv[3], k), 0.0) - TIMES.get((sys.argv[2], k), 0.0)) / n / 1e3
+    tot = sum(us(k) for k in list(d) + list(do))
+    print(f"kernel time per P-frame pair (encoder then decoder, one stream, nothing else on the GPU): {tot:.0f} us")
+    for k, v in sorted(d.items(), key=lambda kv: -us(kv[0])):
         if v:
-            print(f"  {v:5.1f}  {k[:100]}")
+            print(f"  {v:5.1f} x {us(k) / v:7.1f} us = {us(k):7.1f} us ({100 * us(k) / tot:4.1f} %)  {k[:90]}")
     for k, v in sorted(do.items(), key=lambda kv: -kv[1]):
         if v:
-            print(f"  {v:5.1f}  [other] {k[:100]}")
+            print(f"  {v:5.1f} x {us(k) / v:7.1f} us = {us(k):7.1f} us ({100 * us(k) / tot:4.1f} %)  [other] {k[:80]}")
     sys.exit(0)
 
 import torch
