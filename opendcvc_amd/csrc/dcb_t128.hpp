@@ -1,0 +1,524 @@
+// dcb_t128.hpp - DepthConvBlock tail for large maps, fp16: 128-pixel tiles, one 8-wave workgroup per CU (two waves per
+// SIMD, 256 registers each), v_mfma_f32_32x32x16_f16, the FFN gate software-pipelined into each wave's own MFMA stream.
+// Included by dcvc_nn.hip inside its anonymous namespace, after TailParams (same parameter block, plus `wt`).
+//
+// Why this form (measurements: tools/coissue_mb.hip, tools/mb/valu_rate_mb.hip):
+//   * Two waves of one SIMD do NOT overlap matrix and vector work (their times add), but ONE wave's instruction stream
+//     hides ~26 issue cycles of its own vector work behind every 32-cycle 32x32x16 MFMA.  So the gate g(u_lo) + g(u_hi)
+//     of FFN chunk j is cut into pieces that are issued BETWEEN the MFMAs of W4 x v(j-1) and W3 x o -> u(j+1) of the same
+//     wave (two named u accumulator sets, one barrier per chunk, v chunks double-buffered in LDS).  hipcc left alone
+//     issues the gate as one block and sched_group_barrier pipelines of this length do not solve, so the kernel is written
+//     as SLOTS (one MFMA + what is issued in its shadow) separated by __builtin_amdgcn_sched_barrier(0): the source order
+//     is the schedule, while hipcc still allocates registers, counts waits and pads hazards (builtin MFMAs: an inline-asm
+//     MFMA is opaque to it - its result registers are read too early, its operands overwritten too early).
+//   * A single wave issues one plain vector instruction per ~6.8 cycles (transcendental ~9.8); two waves of a SIMD
+//     together one per ~3.4.  The depthwise stage and the epilogues are pure vector work, and with one wave per SIMD
+//     nobody covers an LDS / L2 round trip: hence two waves per SIMD.  Waves w and w + 4 own the same channels and split
+//     the 128 pixels; they read the same weight fragments (the second read hits in L1).
+//   * A weight fragment read from L2 feeds 128 pixels of one CU (the 64-pixel tiles at two workgroups per CU read every
+//     fragment from L2 twice per 128 pixels, and their stream ran into the ~36 B/clk/CU the L2 -> L1 path delivers).
+//   * The weights of the whole tail are packed per channel quarter in CONSUMPTION ORDER (W2, then W3 / W4 interleaved
+//     chunk by chunk): one linear stream of 1 KiB fragments, read through a register ring D fragments deep that never
+//     drains at a phase boundary (buffer loads: scalar descriptor + scalar running offset, no vector address arithmetic).
+// Decomposition: wave w = (channel quarter cq = w & 3, pixel half ph = w >> 2).  It owns output channels
+// [C/4 cq, C/4 (cq+1)) of the C-wide GEMMs (W2, W4) and, per FFN chunk of 64 v columns, the 16 columns [16 cq, +16), for its
+// 64 pixels: its W3 tile has 32 rows = 16 u_lo rows | the 16 u_hi rows they pair with, so a pair lands in ONE lane
+// (registers r and r + 8 of the 32x32 accumulator tile).
+// Same store points / roundings as dcb_tail_kernel (d, W2 d + b2, o, v, r, out): the fp16 oracle covers both.
+#pragma once
+
+namespace t128 {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int TW = 16, TH = 8, M = TW * TH;   // 128 pixels per workgroup
+constexpr int NW = 8, NTHR = NW * 64;
+constexpr int PT = M / 32;                    // pixel tiles of 32 (MFMA N) per workgroup
+constexpr int PTW = PT / 2;                   // ... per wave (its pixel half)
+constexpr int PAD = 8;                        // LDS row pad (halfs): row stride = 4 dwords mod 8 -> conflict-free ds_read_b128
+                                              // of the 32x32x16 B operand (16 distinct rows per lane group)
+constexpr int VC = 64, LDV = VC + PAD;        // v columns per FFN chunk; row stride of a v chunk buffer
+constexpr int HALO = (TH + 2) * (TW + 2);     // 180 pixels
+constexpr int DW_SLAB = 64, LDS_S = DW_SLAB + PAD;
+
+template <int C>
+struct Cfg {
+    static_assert(C % 128 == 0, "four channel quarters x whole 32-channel tiles");
+    static constexpr int NT = C / 32;                 // output channel tiles
+    static constexpr int NTW = NT / 4;                // ... per channel quarter
+    static constexpr int KS = C / 16;                 // k-steps over C
+    static constexpr int NCH = 2 * C / VC;            // FFN chunks
+    static constexpr int F4 = 4 * NTW;                // fragments of one W4 chunk pass
+    // ring depth: fragments requested ahead of their use.  Every phase's ring slots are static: phases start at a
+    // compile-time offset into the ring
+    static constexpr int D = F4;
+    static constexpr int LDX = C + PAD;
+    static constexpr int FRAGS = KS * NTW + NCH * KS + NCH * F4;   // fragments per channel quarter
+    static constexpr int STREAM = FRAGS + D;          // + D dummies: the ring refill never needs a clamp
+    static constexpr size_t v_elems = (size_t)2 * M * LDV > (size_t)2 * HALO * LDS_S ? (size_t)2 * M * LDV : (size_t)2 * HALO * LDS_S;
+    static constexpr size_t LDS = ((size_t)M * LDX + v_elems) * sizeof(half_t);
+    static_assert(NCH % 2 == 0 && NCH >= 4, "the chunk loop is unrolled by two");
+    // ring offsets (fragments consumed so far, mod D) at the start of: u(0), step 0, the odd / even steps of the loop,
+    // the last step, the final W4 pass
+    static constexpr int OFF_U0 = (KS * NTW) % D;
+    static constexpr int OFF_S0 = (OFF_U0 + KS) % D;
+    static constexpr int OFF_ODD = (OFF_S0 + KS) % D;
+    static constexpr int OFF_EVEN = (OFF_ODD + F4 + KS) % D;
+    static_assert((2 * (F4 + KS)) % D == 0, "the two-step loop body must turn the ring a whole number of times");
+    static constexpr int OFF_LAST = OFF_ODD;
+    static constexpr int OFF_FIN = (OFF_LAST + F4) % D;
+};
+
+__device__ __forceinline__ floatx16 mfma32(const half8& a, const half8& b, const floatx16& c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// C/D layout of the 32x32 tile: lane (pl = lane & 31 -> pixel, hh = lane >> 5), register reg -> row (channel)
+// (reg & 3) + 8 (reg >> 2) + 4 hh: four quads of 4 consecutive channels at 8 g + 4 hh, g = 0..3.
+
+template <int C>
+__global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
+{
+    using TR = Traits<half_t>;
+    using CF = Cfg<C>;
+    constexpr int NTW = CF::NTW, KS = CF::KS, NCH = CF::NCH, D = CF::D, LDX = CF::LDX, V = 8, GC = C / V;
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    half_t* bufX = reinterpret_cast<half_t*>(smem);
+    half_t* bufV = bufX + M * LDX;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cqw = wave & 3, ph = wave >> 2;          // channel quarter, pixel half
+    const int pl = lane & 31, hh = lane >> 5;
+    const int tiles_x = (p.W + TW - 1) / TW;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const half_t* a = reinterpret_cast<const half_t*>(p.a);
+    const half_t* ident = reinterpret_cast<const half_t*>(p.ident);
+    [[maybe_unused]] unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
+    STAMP(ts0);
+
+    // ---- weight stream of this wave's channel quarter: ring of D fragments, refilled right after use
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.wt)) + (size_t)cqw * CF::STREAM * 1024, 0, CF::STREAM * 1024, 0x00020000);
+    const int wlane = lane * 16;
+    int woff = 0;
+    auto wload = [&]() __attribute__((always_inline)) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, woff, 0);
+        woff += 1024;
+        return __builtin_bit_cast(half8, v);
+    };
+    half8 ring[D];
+
+    // ---- the global reads of the prologue are requested up front: the activation tile + halo in 64-channel slabs
+    // (registers), later the identity rows
+    constexpr int HW_ = TW + 2, GS = DW_SLAB / V, NLD = (HALO * GS + NTHR - 1) / NTHR;
+    constexpr int nslab = C / DW_SLAB;
+    const half_t* wd = reinterpret_cast<const half_t*>(p.wd);
+    const int dcs = (tid % GS) * V;                      // this thread's channel group inside a slab
+    // halo pixel of load k of this thread: element offset of its row in `a` (or -1 outside the picture), the same for
+    // every slab
+    int hoff[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int hp = tid / GS + k * (NTHR / GS);
+        const int y = ty0 - 1 + hp / HW_, x = tx0 - 1 + hp % HW_;
+        hoff[k] = (hp < HALO && y >= 0 && y < p.H && x >= 0 && x < p.W) ? (y * p.W + x) * (int)p.lda + dcs : -1;
+    }
+    Vec16 pre[nslab][NLD];
+    auto fetch = [&](int slab) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            Vec16 v = VEC16_ZERO;
+            if (hoff[k] >= 0) v = *reinterpret_cast<const Vec16*>(a + hoff[k] + slab * DW_SLAB);
+            pre[slab][k] = v;
+        }
+    };
+    Vec16 wtap[9], wtap_n[9];
+    floatx4 bd0, bd1, bd0_n, bd1_n;
+    auto taps_fetch = [&](int slab) __attribute__((always_inline)) {
+        const int c = slab * DW_SLAB + dcs;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wtap_n[t] = *reinterpret_cast<const Vec16*>(wd + t * C + c);
+        bd0_n = load_f4(p.bd + c);
+        bd1_n = load_f4(p.bd + c + 4);
+    };
+    fetch(0);
+    taps_fetch(0);
+#pragma unroll
+    for (int sl = 1; sl < nslab; ++sl) fetch(sl);
+    constexpr int NID = M * GC / NTHR;
+    static_assert((M * GC) % NTHR == 0, "identity pass");
+    // identity / output pass, item k of this thread -> (pixel m, channel group c); where the thread count is a multiple of
+    // the groups per pixel a thread keeps its channel group (no division per item)
+    auto idmap = [&](int k, int& m, int& c) __attribute__((always_inline)) {
+        if constexpr (NTHR % GC == 0) {
+            c = (tid % GC) * V;
+            m = tid / GC + k * (NTHR / GC);
+        } else {
+            const int it = tid + k * NTHR;
+            m = it / GC;
+            c = (it - m * GC) * V;
+        }
+    };
+    Vec16 idv[NID];
+    auto ident_fetch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NID; ++k) {
+            int m, icg;
+            idmap(k, m, icg);
+            const int y = ty0 + m / TW, x = tx0 + m % TW;
+            idv[k] = VEC16_ZERO;
+            if (y < p.H && x < p.W) idv[k] = *reinterpret_cast<const Vec16*>(ident + ((long)y * p.W + x) * p.ldi + icg);
+        }
+    };
+
+    // ---- depthwise 3x3 (zero padding) + bias -> d in bufX.  A slab goes registers -> one of two LDS halo buffers
+    // (bufV region) -> taps; one barrier per slab.
+    {
+        constexpr int MSTEP = NTHR / GS, ITER = M / MSTEP;
+        static_assert(M % MSTEP == 0 && ITER % 2 == 0, "depthwise pixel loop");
+        const int m0 = tid / GS;
+#pragma unroll
+        for (int slab = 0; slab < nslab; ++slab) {
+            half_t* hb = bufV + (slab & 1) * (HALO * LDS_S);
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int hp = tid / GS + k * (NTHR / GS);
+                if (hp < HALO) *reinterpret_cast<Vec16*>(hb + hp * LDS_S + dcs) = pre[slab][k];
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wtap[t] = wtap_n[t];
+            bd0 = bd0_n;
+            bd1 = bd1_n;
+            if (slab + 1 < nslab) taps_fetch(slab + 1);
+            if (slab == nslab - 2) ident_fetch();   // (registers of the first slabs are free again; two slabs of time to arrive)
+            if (slab == nslab - 1) {                // first turn of the weight ring: lands underneath the last slab
+#pragma unroll
+                for (int k = 0; k < D; ++k) ring[k] = wload();
+            }
+            __syncthreads();
+            const int c = slab * DW_SLAB + dcs;
+            auto taps_load = [&](int m, Vec16 (&v)[9]) __attribute__((always_inline)) {
+                const int my = m / TW, mx = m % TW;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        v[ky * 3 + kx] = *reinterpret_cast<const Vec16*>(hb + ((my + ky) * HW_ + mx + kx) * LDS_S + dcs);
+            };
+            auto taps_apply = [&](int m, const Vec16 (&v)[9]) __attribute__((always_inline)) {
+                float sacc[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) sacc[j] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) fma_vec16<half_t>(v[t], wtap[t], sacc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sacc[j] = sacc[j] + bd0[j];
+                    sacc[4 + j] = sacc[4 + j] + bd1[j];
+                }
+                lds_store_vec<half_t>(bufX, LDX, m, c, pack16<half_t>(sacc));
+            };
+            Vec16 ta[9], tb[9];
+            taps_load(m0, ta);
+#pragma unroll
+            for (int it = 0; it < ITER; it += 2) {
+                const int ma = m0 + it * MSTEP, mb = ma + MSTEP, mc = mb + MSTEP;
+                taps_load(mb, tb);
+                taps_apply(ma, ta);
+                if (it + 2 < ITER) taps_load(mc, ta);
+                taps_apply(mb, tb);
+            }
+        }
+        __syncthreads();
+    }
+    STAMP(ts1);
+
+    // LDS operand addresses of this lane: pixel row pl of this wave's pixel tile t (tile ph * PTW + t of the workgroup),
+    // k offset 8 hh
+    const int prow = (ph * PTW) * 32 + pl;
+    const half_t* xb = bufX + prow * LDX + 8 * hh;
+    auto bfrag_x = [&](int t, int s) __attribute__((always_inline)) {
+        return *reinterpret_cast<const half8*>(xb + t * 32 * LDX + s * 16);
+    };
+
+    // ---- GEMM2: W2 d (this wave's channel quarter x its 64 pixels)
+    floatx16 acc[NTW][PTW];
+    {
+        half8 bc[PTW], bn[PTW];
+#pragma unroll
+        for (int t = 0; t < PTW; ++t) bc[t] = bfrag_x(t, 0);
+        floatx16 zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int q = 0; q < NTW * PTW; ++q) {
+                const int i = q / PTW, t = q % PTW, k = (s * NTW + i) % D;
+                if (s + 1 < KS && q < PTW) bn[q] = bfrag_x(q, s + 1);
+                acc[i][t] = mfma32(ring[k], bc[t], s == 0 ? zero : acc[i][t]);
+                if (t == PTW - 1) ring[k] = wload();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < PTW; ++t) bc[t] = bn[t];
+        }
+    }
+    STAMP(ts2);
+    __syncthreads();   // every wave has finished reading d
+    // (W2 d + b2) -> fp16 -> bufX
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int chb = 32 * (cqw * NTW + i) + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const floatx4 bias = load_f4(p.b2 + chb + 8 * g);
+#pragma unroll
+            for (int t = 0; t < PTW; ++t) {
+                floatx4 v = {acc[i][t][4 * g], acc[i][t][4 * g + 1], acc[i][t][4 * g + 2], acc[i][t][4 * g + 3]};
+                lds_store_quad<half_t>(bufX, LDX, prow + 32 * t, chb + 8 * g, v + bias);
+            }
+        }
+    }
+    __syncthreads();
+    // o = (W2 d + b2) + x'.  A packed fp16 add IS the fp32 add + rounding of the other kernels: the exact sum of two fp16
+    // numbers rounded to fp32 (24 >= 2 * 11 + 2 bits) and then to fp16 equals the sum rounded once.
+#pragma unroll
+    for (int k = 0; k < NID; ++k) {
+        int m, icg;
+        idmap(k, m, icg);
+        const half8 o = __builtin_bit_cast(half8, lds_load_vec<half_t>(bufX, LDX, m, icg)) + __builtin_bit_cast(half8, idv[k]);
+        lds_store_vec<half_t>(bufX, LDX, m, icg, __builtin_bit_cast(Vec16, o));
+    }
+    __syncthreads();
+
+    STAMP(ts3);
+    // ---- FFN, software-pipelined: step j = [W4 x v(j-1) -> acc] [W3 x o -> u(j+1)] with gate(u(j)) -> v(j) in between
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int t = 0; t < PTW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+    floatx16 ua[PTW], ub[PTW];
+    // u accumulators start at the bias (lane's rows: quads 8 g + 4 hh of u_lo, then of u_hi): the first MFMA of a chain
+    // takes the bias tuple as its C operand.  The bias of chunk j + 2 is requested during step j.
+    const float* b3w = p.b3 + 16 * cqw + 4 * hh;
+    floatx16 biasv;
+    auto bias_load = [&](int j) __attribute__((always_inline)) {
+        j = j < NCH ? j : NCH - 1;
+        const floatx4 l0 = load_f4(b3w + 64 * j), l1 = load_f4(b3w + 64 * j + 8);
+        const floatx4 h0 = load_f4(b3w + 64 * j + 2 * C), h1 = load_f4(b3w + 64 * j + 2 * C + 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            biasv[r] = l0[r];
+            biasv[4 + r] = l1[r];
+            biasv[8 + r] = h0[r];
+            biasv[12 + r] = h1[r];
+        }
+    };
+    // The gate of a chunk = 4 PTW units (pixel tile t = n >> 2, quad g = (n >> 1) & 1, half hf = n & 1) of two pairs
+    // -> v columns 16 cq + 8 g + 4 hh + 2 hf + {0, 1}, each unit cut into six pieces of 8 - 24 issue cycles that are
+    // placed one per MFMA (48 pieces for the 48 MFMAs of a full step).  Same operations as Traits<half_t>::gate2.
+    constexpr int NPIECE = 4 * PTW * 6;
+    float ge[4], gr[4];
+    floatx4 vq;
+    auto gate_piece = [&](const floatx16 (&u)[PTW], half_t* vbuf, int i) __attribute__((always_inline)) {
+        const int n = i / 6, phs = i % 6, t = n >> 2, g = (n >> 1) & 1, hf = n & 1;
+        const float lo0 = u[t][4 * g + 2 * hf], lo1 = u[t][4 * g + 2 * hf + 1];
+        const float hi0 = u[t][8 + 4 * g + 2 * hf], hi1 = u[t][8 + 4 * g + 2 * hf + 1];
+        if (phs == 0) {
+            ge[0] = __builtin_amdgcn_exp2f(lo0);
+            ge[1] = __builtin_amdgcn_exp2f(lo1);
+        } else if (phs == 1) {
+            ge[2] = __builtin_amdgcn_exp2f(hi0);
+            ge[3] = __builtin_amdgcn_exp2f(hi1);
+        } else if (phs == 2) {
+            gr[0] = __builtin_amdgcn_rcpf(1.0f + ge[0]);
+            gr[1] = __builtin_amdgcn_rcpf(1.0f + ge[1]);
+        } else if (phs == 3) {
+            gr[2] = __builtin_amdgcn_rcpf(1.0f + ge[2]);
+            gr[3] = __builtin_amdgcn_rcpf(1.0f + ge[3]);
+        } else if (phs == 4) {
+            vq[2 * hf] = DCVC_FMAF(hi0, gr[2], lo0 * gr[0]);
+        } else {
+            vq[2 * hf + 1] = DCVC_FMAF(hi1, gr[3], lo1 * gr[1]);
+            if (hf == 1) lds_store_quad<half_t>(vbuf, LDV, prow + 32 * t, 16 * cqw + 8 * g + 4 * hh, vq);
+        }
+    };
+    // One pipelined step (chunk j): the k-steps of [W4 x v(j-1) -> acc] (G4: 4 k-steps of NTW fragments) and of
+    // [W3 x o -> u(j+1)] (G3: KS k-steps of one fragment) as a sequence of slots = one MFMA + what is issued in its shadow:
+    // one LDS read of the next k-step's pixel fragments, the ring refill after a fragment's last MFMA, and (GATE) the gate
+    // pieces of chunk j.  OFF: ring slot of the step's first fragment; jb: chunk whose bias is requested.
+    auto step = [&](auto G4c, auto G3c, auto GATEc, auto OFFc, const floatx16 (&ug)[PTW], floatx16 (&un)[PTW], half_t* vcur,
+                    const half_t* vprev, int jb) __attribute__((always_inline)) {
+        constexpr bool G4 = decltype(G4c)::value, G3 = decltype(G3c)::value, GATE = decltype(GATEc)::value;
+        constexpr int OFF = decltype(OFFc)::value;
+        constexpr int N4 = G4 ? 4 : 0, NS = N4 + (G3 ? KS : 0);
+        constexpr int TM = N4 * NTW * PTW + (G3 ? KS * PTW : 0);       // MFMAs (slots) of the step
+        constexpr int PPS = GATE ? (NPIECE + TM - 1) / TM : 0;          // gate pieces per slot
+        auto load_b1 = [&](int idx, int t) __attribute__((always_inline)) {
+            if (idx < N4) return *reinterpret_cast<const half8*>(vprev + (prow + 32 * t) * LDV + 8 * hh + idx * 16);
+            return bfrag_x(t, idx - N4);
+        };
+        half8 bc[PTW], bn[PTW];
+#pragma unroll
+        for (int t = 0; t < PTW; ++t) bc[t] = load_b1(0, t);
+        __builtin_amdgcn_sched_barrier(0);
+        int m = 0;
+#pragma unroll
+        for (int idx = 0; idx < NS; ++idx) {
+            const int nm = idx < N4 ? NTW * PTW : PTW;
+#pragma unroll
+            for (int q = 0; q < NTW * PTW; ++q) {
+                if (q < nm) {
+                    if (idx + 1 < NS && q < PTW) bn[q] = load_b1(idx + 1, q);
+                    const int t = q % PTW;
+                    if (idx < N4) {
+                        const int i = q / PTW, k = (OFF + idx * NTW + i) % D;
+                        acc[i][t] = mfma32(ring[k], bc[t], acc[i][t]);
+                        if (t == PTW - 1) ring[k] = wload();
+                    } else {
+                        const int k = (OFF + N4 * NTW + (idx - N4)) % D;
+                        un[t] = mfma32(ring[k], bc[t], idx == N4 ? biasv : un[t]);   // (first k-step: starts at the bias)
+                        if (t == PTW - 1) ring[k] = wload();
+                        if (idx == N4 && t == PTW - 1) bias_load(jb);                // the next chunk's, into the same registers
+                    }
+                    if constexpr (GATE) {
+#pragma unroll
+                        for (int pp = 0; pp < PPS; ++pp)
+                            if (m * PPS + pp < NPIECE) gate_piece(ug, vcur, m * PPS + pp);
+                    }
+                    ++m;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < PTW; ++t) bc[t] = bn[t];
+        }
+        if constexpr (GATE) __syncthreads();
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    half_t* vA = bufV;
+    half_t* vB = bufV + M * LDV;
+#define T128_OFF(x) std::integral_constant<int, CF::x>{}
+    bias_load(0);
+    step(F_{}, T_{}, F_{}, T128_OFF(OFF_U0), ub, ua, vA, vB, 1);       // prologue: u(0)
+    STAMP(ts4);
+    step(F_{}, T_{}, T_{}, T128_OFF(OFF_S0), ua, ub, vA, vB, 2);
+    for (int j = 1; j + 2 < NCH; j += 2) {
+        step(T_{}, T_{}, T_{}, T128_OFF(OFF_ODD), ub, ua, vB, vA, j + 2);
+        step(T_{}, T_{}, T_{}, T128_OFF(OFF_EVEN), ua, ub, vA, vB, j + 3);
+    }
+    step(T_{}, F_{}, T_{}, T128_OFF(OFF_LAST), ub, ua, vB, vA, 0);
+    step(T_{}, F_{}, F_{}, T128_OFF(OFF_FIN), ub, ua, vA, vB, 0);      // W4 x v(NCH-1)  (NCH - 1 is odd: its v is in buffer B = vprev)
+#undef T128_OFF
+
+    STAMP(ts5);
+    // ---- r = (W4 v + b4) + o, in place in bufX (each element is owned by one lane)
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int chb = 32 * (cqw * NTW + i) + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const floatx4 bias = load_f4(p.b4 + chb + 8 * g);
+#pragma unroll
+            for (int t = 0; t < PTW; ++t) {
+                const floatx4 o = lds_load_quad<half_t>(bufX, LDX, prow + 32 * t, chb + 8 * g);
+                floatx4 v = {acc[i][t][4 * g], acc[i][t][4 * g + 1], acc[i][t][4 * g + 2], acc[i][t][4 * g + 3]};
+                lds_store_quad<half_t>(bufX, LDX, prow + 32 * t, chb + 8 * g, (v + bias) + o);
+            }
+        }
+    }
+    __syncthreads();
+    half_t* out = reinterpret_cast<half_t*>(p.out);
+    if (out != nullptr) {
+#pragma unroll
+        for (int k = 0; k < NID; ++k) {
+            int m, icg;
+            idmap(k, m, icg);
+            const int y = ty0 + m / TW, x = tx0 + m % TW;
+            if (y < p.H && x < p.W) {
+                const long pix = (long)y * p.W + x;
+                float r[V];
+                unpack16<half_t>(lds_load_vec<half_t>(bufX, LDX, m, icg), r);
+                if (p.shortcut) {
+                    float id[V];
+                    unpack16<half_t>(*reinterpret_cast<const Vec16*>(ident + pix * p.ldi + icg), id);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) r[j] = r[j] + id[j];
+                }
+                if (p.q != nullptr) {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) r[j] = r[j] * ((icg + j) < p.c_log ? p.q[icg + j] : 1.0f);
+                }
+                *reinterpret_cast<Vec16*>(out + pix * p.ldo + icg) = pack16<half_t>(r);
+            }
+        }
+    }
+    STAMP(ts6);
+#ifdef DCVC_DIAG
+    if (p.stamps && tid == 0) {
+        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+        o[0] = ts1 - ts0;   // loads + depthwise
+        o[1] = ts2 - ts1;   // GEMM2
+        o[2] = ts3 - ts2;   // (+b2) store, o pass
+        o[3] = ts4 - ts3;   // u(0)
+        o[4] = ts5 - ts4;   // pipelined FFN
+        o[5] = ts6 - ts5;   // r + store
+        o[6] = ts0;
+        o[7] = ts6;
+    }
+#endif
+    if (p.nw1 != nullptr) {
+        // Fused head of the next block / fused 1x1 conv on the tile still in bufX: the 16x16x32 GEMM of gemm_core.hpp in
+        // the k order of dcb_head_kernel / conv_kernel, so the values are bit-identical to the separate launch.
+        constexpr int MT8 = M / 16, NT16 = C / (16 * NW);   // 16-channel tiles per wave (all 128 pixels)
+        using frag_t = typename TR::frag_t;
+        int tiles[NT16];
+#pragma unroll
+        for (int i = 0; i < NT16; ++i) tiles[i] = wave + NW * i;
+        const int pl16 = lane & 15, cq = (lane >> 4) * 4;
+        floatx4 acc1[MT8][NT16];
+        zero_acc(acc1);
+        gemm_acc<half_t, MT8, NT16, 2>(acc1, bufX, LDX, C / KG, reinterpret_cast<const frag_t*>(p.nw1), C / KG, 0, tiles, lane);
+        __syncthreads();   // every wave has finished reading r
+#pragma unroll
+        for (int i = 0; i < NT16; ++i) {
+            const int ch0 = tiles[i] * 16 + cq;
+            const floatx4 bias = load_f4(p.nb1 + ch0);
+            floatx4 qv = {1.f, 1.f, 1.f, 1.f};
+            if (p.nplain && p.nq != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qv[r] = (ch0 + r) < p.n_log ? p.nq[ch0 + r] : 1.0f;
+            }
+#pragma unroll
+            for (int m = 0; m < MT8; ++m) {
+                floatx4 v = acc1[m][i] + bias;
+                if (p.nplain) {
+                    if (p.nq != nullptr) v = v * qv;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = TR::gate(v[r]);
+                }
+                lds_store_quad<half_t>(bufX, LDX, m * 16 + pl16, ch0, v);
+            }
+        }
+        __syncthreads();
+        half_t* na = reinterpret_cast<half_t*>(p.na_out);
+#pragma unroll
+        for (int k = 0; k < NID; ++k) {
+            int m, icg;
+            idmap(k, m, icg);
+            const int y = ty0 + m / TW, x = tx0 + m % TW;
+            if (y < p.H && x < p.W)
+                *reinterpret_cast<Vec16*>(na + ((long)y * p.W + x) * p.nlda + icg) = lds_load_vec<half_t>(bufX, LDX, m, icg);
+        }
+    }
+}
+
+}  // namespace t128

@@ -13,12 +13,6 @@
 
 #include "common.hpp"
 #include "gemm_core.hpp"
-// Experimental pixel-stationary DepthConvBlock tail (dcb_ps.hpp): compiled into the developer build only
-// (make diag: -DDCVC_DIAG -DDCVC_EXPERIMENTAL_PS, selected at run time with DCVC_PS=1).  It is correct (same tests)
-// but measured slower than the channel-split tails below - DESIGN.md section 4 has the numbers and the analysis.
-#ifdef DCVC_EXPERIMENTAL_PS
-#include "dcb_ps.hpp"
-#endif
 
 namespace {
 
@@ -233,6 +227,7 @@ struct TailParams {
     long ldhx;
     const void* hw1;
     const float* hb1;
+    const void* wt;      // dcb_tail128_kernel: the tail's weights as per-wave fragment streams (dcb_t128.hpp)
     int ablate;          // debug: bit0 skip dw, bit1 skip GEMM2, bit2 skip FFN GEMM3, bit3 skip FFN GEMM4
     unsigned long long* stamps;   // diagnostic build only (DCVC_STAMPS): 8 cycle counters per workgroup
 };
@@ -726,6 +721,8 @@ __global__ __launch_bounds__(NW * 64, (TailCfg<MT, NTW, NW>::waves_per_simd)) vo
 #endif
 }
 
+#include "dcb_t128.hpp"
+
 // ------------------------------------------------------------------------------------------
 // Dense convolution as implicit GEMM over (tap, cin)
 struct ConvParams {
@@ -936,27 +933,13 @@ int upload_T(DevBuf& dst, int n, const std::function<float(int)>& get)
     return dst.upload(v.data(), v.size() * sizeof(T));
 }
 
-#ifdef DCVC_EXPERIMENTAL_PS
-// ---- pixel-stationary tail: packing (dcb_ps.hpp) -------------------------------------------------------
-// one 1 KiB A fragment of v_mfma_f32_32x32x16_f16: lane l holds W[row0 + sigma(l & 31)][k0 + 8 (l >> 5) + j], j = 0..7
-inline void ps_put_frag(std::vector<half_t>& buf, const std::function<float(int, int)>& get, int row0, int k0)
-{
-    for (int l = 0; l < 64; ++l)
-        for (int j = 0; j < 8; ++j) buf.push_back((half_t)get(row0 + ps::sigma(l & 31), k0 + 8 * (l >> 5) + j));
-}
-
-inline bool ps_width_ok(int c_p) { return c_p == 256; }   // (320 / 384: register budget)
-#endif
 
 }  // namespace
 
 struct dcvc_dcb {
     int dtype, cin, c, cin_p, c_p, shortcut, adapt;
     DevBuf wa, ba, w1, b1, wd, bd, w2, b2, w3, b3, w4, b4;
-    // pixel-stationary tail (dcb_ps.hpp; fp16, widths 256 / 320 / 384): the tail's weights in consumption order,
-    // this block's first conv in the same form (for the previous block's fused head), and the small tables
-    int ps = 0;
-    DevBuf ps_tail, ps_head, ps_tbl;
+    DevBuf wt128;   // fp16, widths 256 / 384: W2 | W3 | W4 once more as the fragment streams of dcb_tail128_kernel
 };
 
 struct dcvc_conv {
@@ -1009,69 +992,99 @@ int set_lds(K kernel, size_t bytes)
     return 0;
 }
 
-#ifdef DCVC_EXPERIMENTAL_PS
+
+// ---- dcb_tail128_kernel: weight streams (one per wave, 1 KiB fragments of v_mfma_f32_32x32x16_f16's A operand in the
+// order the wave consumes them) and launch
 template <int C>
-int launch_tail_ps(const ps::Params& pp, int H, int W, hipStream_t st)
+int pack_t128(DevBuf& dst, const std::function<float(int, int)>& W2, const std::function<float(int, int)>& W3,
+              const std::function<float(int, int)>& W4)
 {
-    const int grid = ((H + ps::TH - 1) / ps::TH) * ((W + ps::TW - 1) / ps::TW);
-    const size_t lds = ps::Cfg<C>::LDS_BYTES;
-    int rc = set_lds(ps::dcb_tail_ps_kernel<C>, lds);
+    using CF = t128::Cfg<C>;
+    std::vector<half_t> buf((size_t)4 * CF::STREAM * 512, (half_t)0.f);
+    for (int wave = 0; wave < 4; ++wave) {
+        size_t f = 0;
+        auto put = [&](const std::function<float(int, int)>& get, const std::function<int(int)>& row, int s) {
+            half_t* o = &buf[((size_t)wave * CF::STREAM + f) * 512];
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) o[l * 8 + j] = (half_t)get(row(l & 31), 16 * s + 8 * (l >> 5) + j);
+            ++f;
+        };
+        auto g3 = [&](int j) {   // u tile of chunk j: 16 u_lo rows | the 16 u_hi rows they pair with (physical halves 2 C wide)
+            for (int s = 0; s < CF::KS; ++s)
+                put(W3, [&](int r) { return (r < 16 ? 0 : 2 * C - 16) + 64 * j + 16 * wave + r; }, s);
+        };
+        auto g4 = [&](int j) {
+            for (int s4 = 0; s4 < 4; ++s4)
+                for (int i = 0; i < CF::NTW; ++i) put(W4, [&](int r) { return 32 * (wave * CF::NTW + i) + r; }, 4 * j + s4);
+        };
+        for (int s = 0; s < CF::KS; ++s)
+            for (int i = 0; i < CF::NTW; ++i) put(W2, [&](int r) { return 32 * (wave * CF::NTW + i) + r; }, s);
+        g3(0);
+        for (int j = 0; j < CF::NCH; ++j) {
+            if (j >= 1) g4(j - 1);
+            if (j + 1 < CF::NCH) g3(j + 1);
+        }
+        g4(CF::NCH - 1);
+        if (f != (size_t)CF::FRAGS) {
+            dcvc::set_error("pack_t128: %zu fragments packed, %d expected", f, CF::FRAGS);
+            return dcvc::E_ARG;
+        }
+    }
+    return dst.upload(buf.data(), buf.size() * sizeof(half_t));
+}
+
+inline bool t128_width_ok(int c_p) { return c_p == 256 || c_p == 384; }
+
+// DCVC_T128=0 keeps the 64-pixel tails on large maps (A/B measurements; both forms pass the same layer tests)
+static bool t128_enabled()
+{
+    static const bool on = !(getenv("DCVC_T128") && atoi(getenv("DCVC_T128")) == 0);
+    return on;
+}
+
+template <int C>
+int launch_tail128(const TailParams& tp, int H, int W, hipStream_t st)
+{
+    const int grid = ((H + t128::TH - 1) / t128::TH) * ((W + t128::TW - 1) / t128::TW);
+    const size_t lds = t128::Cfg<C>::LDS;
+    int rc = set_lds(t128::dcb_tail128_kernel<C>, lds);
     if (rc) return rc;
-#ifdef DCVC_DIAG
+#ifdef DCVC_DIAG      // developer build only (make diag): in-kernel phase stamps, median over the workgroups
     static const bool want_stamps = getenv("DCVC_STAMPS") != nullptr;
-    if (want_stamps) {   // developer build only: median cycles per phase over the workgroups
-        ps::Params q = pp;
-        DCVC_HIP(hipMalloc(&q.stamps, (size_t)grid * 20 * sizeof(unsigned long long)));
-        hipLaunchKernelGGL((ps::dcb_tail_ps_kernel<C>), dim3(grid), dim3(ps::NTHR), lds, st, q);
+    if (want_stamps) {
+        TailParams q = tp;
+        DCVC_HIP(hipMalloc(&q.stamps, (size_t)grid * 8 * sizeof(unsigned long long)));
+        hipLaunchKernelGGL((t128::dcb_tail128_kernel<C>), dim3(grid), dim3(t128::NTHR), lds, st, q);
         DCVC_HIP(hipStreamSynchronize(st));
-        std::vector<unsigned long long> hs((size_t)grid * 20);
+        std::vector<unsigned long long> hs((size_t)grid * 8);
         DCVC_HIP(hipMemcpy(hs.data(), q.stamps, hs.size() * 8, hipMemcpyDeviceToHost));
         (void)hipFree(q.stamps);
         static int printed = 0;
         if (printed++ % 16 == 15) {
-            const char* names[7] = {"prologue", "gemm2+dw", "o", "ffn", "r", "store", "head"};
-            unsigned long long t0 = ~0ull, t1 = 0;
-            fprintf(stderr, "[ps stamps C=%d grid=%d]", C, grid);
-            for (int k = 0; k < 7; ++k) {
+            const char* names[6] = {"fill+dw", "gemm2", "o_pass", "u0", "ffn", "r+store"};
+            fprintf(stderr, "[t128 stamps C=%d grid=%d]", C, grid);
+            for (int k = 0; k < 6; ++k) {
                 std::vector<unsigned long long> v(grid);
-                for (int b = 0; b < grid; ++b) v[b] = hs[(size_t)b * 8 + k + 1] - hs[(size_t)b * 8 + k];
+                for (int b = 0; b < grid; ++b) v[b] = hs[(size_t)b * 8 + k];
                 std::sort(v.begin(), v.end());
                 fprintf(stderr, " %s=%llu", names[k], v[grid / 2]);
             }
-            std::vector<unsigned long long> st0(grid), tot(grid);
+            unsigned long long t0 = ~0ull, t1 = 0;
+            std::vector<unsigned long long> du(grid);
             for (int b = 0; b < grid; ++b) {
-                t0 = std::min(t0, hs[(size_t)b * 8]);
+                t0 = std::min(t0, hs[(size_t)b * 8 + 6]);
                 t1 = std::max(t1, hs[(size_t)b * 8 + 7]);
-                tot[b] = hs[(size_t)b * 8 + 7] - hs[(size_t)b * 8];
+                du[b] = hs[(size_t)b * 8 + 7] - hs[(size_t)b * 8 + 6];
             }
-            for (int b = 0; b < grid; ++b) st0[b] = hs[(size_t)b * 8] - t0;
-            std::sort(st0.begin(), st0.end());
-            std::sort(tot.begin(), tot.end());
-            fprintf(stderr, " | total med %llu max %llu\n", tot[grid / 2], tot[grid - 1]);
-            const char* wn[3] = {"lds_drain", "barrier", "commit(vmcnt)"};
-            fprintf(stderr, "   ring_step waits per wave (median over waves):");
-            for (int k = 0; k < 3; ++k) {
-                std::vector<unsigned long long> v((size_t)grid * 4);
-                for (size_t w = 0; w < v.size(); ++w) v[w] = hs[(size_t)grid * 8 + w * 3 + k];
-                std::sort(v.begin(), v.end());
-                fprintf(stderr, " %s=%llu", wn[k], v[v.size() / 2]);
-            }
-            fprintf(stderr, "\n");
+            std::sort(du.begin(), du.end());
+            fprintf(stderr, " | wg total min/med/max %llu %llu %llu span %llu\n", du[0], du[grid / 2], du[grid - 1], t1 - t0);
         }
         return 0;
     }
 #endif
-    hipLaunchKernelGGL((ps::dcb_tail_ps_kernel<C>), dim3(grid), dim3(ps::NTHR), lds, st, pp);
+    hipLaunchKernelGGL((t128::dcb_tail128_kernel<C>), dim3(grid), dim3(t128::NTHR), lds, st, tp);
     return 0;
 }
-
-// maps that give every CU a 128-pixel tile (136 x 240: 255 tiles); developer build only, DCVC_PS=1 selects it
-static bool use_ps(const dcvc_dcb* h, int H, int W)
-{
-    static const int env = getenv("DCVC_PS") ? atoi(getenv("DCVC_PS")) : 0;
-    return env != 0 && h->ps && (long)H * W >= 12000;
-}
-#endif
 
 // chained launches: this block's `a` lives in scratch slot a_slot (already there if head_done: the previous
 // block's tail produced it); if next != NULL this block's tail also produces next's `a` in the other slot
@@ -1187,41 +1200,6 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         tp.nq = ch.conv_q;
         tp.n_log = ch.conv->cout;
     }
-#ifdef DCVC_EXPERIMENTAL_PS
-    if constexpr (sizeof(T) == 2) {
-        if (use_ps(h, H, W) && (!ch.next || ch.next->ps) && !ch.conv) {
-            ps::Params pp{};
-            pp.a = tp.a;
-            pp.lda = tp.lda;
-            pp.ident = tp.ident;
-            pp.ldi = tp.ldi;
-            pp.H = H;
-            pp.W = W;
-            pp.c_log = h->c;
-            pp.stream = h->ps_tail.p;
-            pp.tables = h->ps_tbl.p;
-            pp.shortcut = h->shortcut;
-            pp.q = quant;
-            pp.out = out;
-            pp.ldo = ldo;
-            if (ch.next) {
-                pp.nstream = ch.next->ps_head.p;
-                pp.nb1 = (const float*)ch.next->b1.p;
-                pp.na_out = a_next;
-                pp.nlda = C;
-            }
-            int rc = dcvc::E_ARG;
-            switch (C) {
-            case 256: rc = launch_tail_ps<256>(pp, H, W, st); break;
-            default: dcvc::set_error("pixel-stationary tail: width %d not instantiated", C); break;
-            }
-            if (rc) return rc;
-            DCVC_LAUNCH_CHECK();
-            if (ev) DCVC_HIP(hipEventRecord(ev[2], st));
-            return 0;
-        }
-    }
-#endif
 #ifdef DCVC_DIAG      // developer build only (make diag): phase ablation / in-kernel stamps
     {
         static const int abl = getenv("DCVC_ABLATE") ? atoi(getenv("DCVC_ABLATE")) : 0;
@@ -1234,6 +1212,17 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         tp.stamps = d_stamps;
     }
 #endif
+    if constexpr (sizeof(T) == 2 && MT == 4 && (NTW == 4 || NTW == 6)) {
+        // large maps, widths 256 / 384: 128-pixel tiles, one 4-wave workgroup per CU, gate pipelined into the MFMA stream
+        if (h->wt128.p != nullptr && t128_enabled() && !head_in) {
+            tp.wt = h->wt128.p;
+            int rc = launch_tail128<NTW * 64>(tp, H, W, st);
+            if (rc) return rc;
+            DCVC_LAUNCH_CHECK();
+            if (ev) DCVC_HIP(hipEventRecord(ev[2], st));
+            return 0;
+        }
+    }
     {
         // Widths of 384 and up (6+ channel tiles per wave) fit one workgroup per CU only.  Eight waves
         // (two per SIMD, half the channel tiles each, <= 256 VGPRs) give every SIMD a second wave of the
@@ -1438,47 +1427,13 @@ int dcvc_dcb_create(int dtype, int cin, int c, int shortcut, const float* adapto
     rc |= upload_f32(h->b3, 4 * Cp, [&](int n) { const int rr = u_row(n); return rr >= 0 ? ka * b3[rr] : 0.f; });
     rc |= pack_any(dtype, h->w4, Cp, 2 * Cp, [&](int n, int k) { return (n < C && k < 2 * C) ? w4[(size_t)n * 2 * C + k] / ka : 0.f; });
     rc |= upload_f32(h->b4, Cp, [&](int n) { return n < C ? b4[n] : 0.f; });
-#ifdef DCVC_EXPERIMENTAL_PS
-    if (rc == 0 && dtype == DCVC_F16 && ps_width_ok(Cp)) {
-        // the same (pre-scaled, fp16) weights once more, as the fragment stream of dcb_tail_ps_kernel
-        const int NT = Cp / 32, KS = Cp / 16;
-        auto W1 = [&](int n, int k) { return (n < C && k < C) ? ka * w1[(size_t)n * C + k] : 0.f; };
+    if (rc == 0 && dtype == DCVC_F16 && t128_width_ok(Cp)) {
+        // the same (pre-scaled, fp16) tail weights once more, as the fragment streams of dcb_tail128_kernel
         auto W2 = [&](int n, int k) { return (n < C && k < C) ? w2[(size_t)n * C + k] : 0.f; };
         auto W3 = [&](int n, int k) { const int rr = u_row(n); return (rr >= 0 && k < C) ? ka * w3[(size_t)rr * C + k] : 0.f; };
         auto W4 = [&](int n, int k) { return (n < C && k < 2 * C) ? w4[(size_t)n * 2 * C + k] / ka : 0.f; };
-        std::vector<half_t> st;
-        st.reserve((size_t)7 * Cp * Cp);
-        for (int i = 0; i < NT; ++i)                       // W2, k-outer: slot i = k-steps 2 i, 2 i + 1
-            for (int kk = 0; kk < 2; ++kk)
-                for (int t = 0; t < NT; ++t) ps_put_frag(st, W2, 32 * t, 16 * (2 * i + kk));
-        auto put_u = [&](int j) {                          // W3: u_lo tile j, u_hi tile j (one slot each)
-            for (int half = 0; half < 2; ++half)
-                for (int ks = 0; ks < KS; ++ks) ps_put_frag(st, W3, half * 2 * Cp + 32 * j, 16 * ks);
-        };
-        put_u(0);
-        for (int j = 0; j < KS; ++j) {
-            if (j + 1 < KS) put_u(j + 1);
-            for (int s2 = 0; s2 < 2; ++s2)                 // W4 slice of v tile j: k = 32 j + 16 s
-                for (int t = 0; t < NT; ++t) ps_put_frag(st, W4, 32 * t, 32 * j + 16 * s2);
-        }
-        rc |= h->ps_tail.upload(st.data(), st.size() * sizeof(half_t));
-        std::vector<half_t> hd;
-        for (int t = 0; t < NT; ++t)                       // W1, tile-outer
-            for (int ks = 0; ks < KS; ++ks) ps_put_frag(hd, W1, 32 * t, 16 * ks);
-        rc |= h->ps_head.upload(hd.data(), hd.size() * sizeof(half_t));
-        // tables: wd [9][Cp] f16 | bd | b2 | b3 [4 Cp] | b4   (fp32)
-        std::vector<char> tb((size_t)46 * Cp);
-        half_t* twd = reinterpret_cast<half_t*>(tb.data());
-        for (int i = 0; i < 9 * Cp; ++i) twd[i] = (half_t)dwget(i);
-        float* tf = reinterpret_cast<float*>(tb.data() + 18 * Cp);
-        for (int n = 0; n < Cp; ++n) tf[n] = n < C ? bd[n] : 0.f;
-        for (int n = 0; n < Cp; ++n) tf[Cp + n] = n < C ? b2[n] : 0.f;
-        for (int n = 0; n < 4 * Cp; ++n) { const int rr = u_row(n); tf[2 * Cp + n] = rr >= 0 ? ka * b3[rr] : 0.f; }
-        for (int n = 0; n < Cp; ++n) tf[6 * Cp + n] = n < C ? b4[n] : 0.f;
-        rc |= h->ps_tbl.upload(tb.data(), tb.size());
-        h->ps = rc == 0;
+        rc |= Cp == 256 ? pack_t128<256>(h->wt128, W2, W3, W4) : pack_t128<384>(h->wt128, W2, W3, W4);
     }
-#endif
     if (rc) return rc < 0 ? rc : dcvc::E_MEM;
     *out = h.release();
     return 0;

@@ -108,8 +108,9 @@ def test_depth_conv_block(case, dtype):
 
 @pytest.mark.parametrize("c", [128, 256, 320, 368, 512])
 def test_depth_conv_block_large_map_fp16(c):
-    """Maps of 12 000+ pixels take the 64-pixel-tile kernels (two workgroups per CU up to 256 channels,
-    eight-wave workgroups above, the ragged one at 320): same check as above, edge tiles included."""
+    """Maps of 12 000+ pixels take the large-map kernels (widths 256 / 384: 128-pixel tiles, one workgroup per CU,
+    dcb_tail128_kernel; 64-pixel tiles otherwise: two workgroups per CU at 128, eight-wave workgroups above, the ragged
+    one at 320): same check as above, edge tiles included."""
     from opendcvc_amd import nn
     H, W = 101, 123
     rng = _rng(300 + c)
@@ -126,7 +127,7 @@ def test_depth_conv_block_large_map_fp16(c):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-@pytest.mark.parametrize("c,hw", [(256, (21, 19)), (128, (9, 33)), (368, (12, 11)), (320, (101, 123))])
+@pytest.mark.parametrize("c,hw", [(256, (21, 19)), (128, (9, 33)), (368, (12, 11)), (320, (101, 123)), (256, (101, 123)), (368, (99, 125))])
 def test_chained_blocks_equal_separate_calls(c, hw, dtype):
     """dcb_chain (the next block's first conv computed in the previous block's epilogue) is bit-identical to
     calling the blocks one by one, in both modes; a block with a quant step or a different width ends a chain.
@@ -157,7 +158,7 @@ def test_chained_blocks_equal_separate_calls(c, hw, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("quant", [False, True])
-@pytest.mark.parametrize("c,hw", [(256, (21, 19)), (128, (9, 33)), (320, (40, 37)), (320, (101, 123))])
+@pytest.mark.parametrize("c,hw", [(256, (21, 19)), (128, (9, 33)), (320, (40, 37)), (320, (101, 123)), (256, (101, 123)), (384, (99, 125))])
 def test_chain_then_conv_equals_separate_calls(c, hw, quant, dtype):
     """dcb_chain(..., then_conv=conv) (the 1x1 conv after a run of blocks computed in the last block's tail, the run's
     own result never written: dcvc_dcb_forward_then_conv) = the run followed by the conv kernel, bit for bit, with and
