@@ -20,7 +20,7 @@ codes its own independent stream (weak scaling, no data-path collective; the wei
 broadcast once from rank 0 over RCCL).  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline     dominant kernel (dcb_tail_kernel<f16>, C = 256 at 136x240): algorithmic FLOP per
+  roofline     dominant kernel (dcb_tail128_kernel<256>: the DepthConvBlock tail, C = 256 at 136x240): algorithmic FLOP per
                launch / HIP-event time on its stream, against the 2.5 PFLOP/s dense f16 MFMA peak.
   cpu_baseline the CPU oracle (port of the reference's torch fallback path) on the host cores: P frames of a
                1/16-area crop (480x272), 2 warm-up + 3 timed frames, at 1 thread (what the reference harness
@@ -105,13 +105,13 @@ def roofline_leg(p_net, device, dtype):
     flop = 2.0 * P * (7 * C * C + 9 * C)               # W2 + W3(4x) + W4(2x) + depthwise, per launch
     achieved = flop / (burst.value * 1e-3) / 1e12
     traffic = None
-    pmc = os.path.join(REPO, "profiles", "pmc_dcb_tail.json")
+    pmc = os.path.join(REPO, "profiles", "r03_pmc_dcb_tail.json")
     if os.path.exists(pmc) and (H, W) == (136, 240):     # the PMC passes were taken at this shape
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    return {"kernel": "dcb_tail_kernel<f16,MT=4,NTW=4> (C=256, %dx%d)" % (H, W), "bound": "mfma",
+    return {"kernel": "dcb_tail128_kernel<256> (DepthConvBlock tail, f16, C=256, %dx%d, 128-pixel tiles)" % (H, W), "bound": "mfma",
             "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
             "flop_per_launch": flop, "kernel_ms": round(burst.value, 4),

@@ -288,6 +288,20 @@ int dcvc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, uint32_t* 
 /* pinned host staging buffers for the device <-> coder hand-off (hipHostMalloc / hipHostFree) */
 void* dcvc_host_alloc(size_t bytes);
 void dcvc_host_free(void* p);
+/* the device address of a dcvc_host_alloc buffer (kernels may read / write pinned host memory in place) */
+void* dcvc_host_device_ptr(void* host);
+/* Encoder symbol hand-off without a copy command (replaces the reference's boolean-mask compaction + .cpu(),
+ * src/layers/cuda_inference.py:159, src/models/entropy_models.py:46-52, and its device synchronisation for the size):
+ * `packed` = n_parts arrays of n_per_part int16 (sym << 8 | index, low byte 0xFF = skipped, as dcvc_prior_enc_step writes
+ * them).  The kept entries of part p are written IN ORDER to out_host[p * n_per_part ...] and their number to
+ * counts_host[p]; both are dcvc_host_alloc buffers that the kernels write in place over the host link.  workspace: device,
+ * DCVC_COMPACT_BLOCKS * n_parts int32.  The host may read the buffers once the stream has passed this point. */
+#define DCVC_COMPACT_BLOCKS 256
+int dcvc_compact_symbols(const int16_t* packed, int n_per_part, int n_parts, int16_t* out_host, int32_t* counts_host,
+                         int32_t* workspace, void* stream);
+/* dst[0..n) = src[0..n) on the device by a kernel (the per-frame row of the quantisation tables: src/models/video_model.py:303-305
+ * slices them per call; a runtime copy command costs an order of magnitude more than the kernel) */
+int dcvc_copy_f32(float* dst, const float* src, int n, void* stream);
 /* stream-ordered copies (hipMemcpyAsync) and event-free host wait for a stream */
 int dcvc_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
 int dcvc_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);

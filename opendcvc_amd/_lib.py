@@ -108,6 +108,9 @@ _SIGS = {
     "dcvc_pmf_to_quantized_cdf": (_I, [_P, _I, _I, _P]),
     "dcvc_host_alloc": (_P, [c_size_t]),
     "dcvc_host_free": (None, [_P]),
+    "dcvc_host_device_ptr": (_P, [_P]),
+    "dcvc_compact_symbols": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "dcvc_copy_f32": (_I, [_P, _P, _I, _P]),
     "dcvc_memcpy_d2h": (_I, [_P, _P, c_size_t, _P]),
     "dcvc_memcpy_h2d": (_I, [_P, _P, c_size_t, _P]),
     "dcvc_stream_sync": (_I, [_P]),

@@ -51,6 +51,16 @@ void dcvc_host_free(void* p)
     if (p) (void)hipHostFree(p);
 }
 
+void* dcvc_host_device_ptr(void* host)
+{
+    void* d = nullptr;
+    if (!host || hipHostGetDevicePointer(&d, host, 0) != hipSuccess) {
+        dcvc::set_error("hipHostGetDevicePointer failed");
+        return nullptr;
+    }
+    return d;
+}
+
 int dcvc_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream)
 {
     DCVC_REQUIRE(dst_host && src_dev, "dcvc_memcpy_d2h: null pointer");

@@ -39,7 +39,10 @@ constexpr int PAD = 8;                        // LDS row pad (halfs): row stride
                                               // of the 32x32x16 B operand (16 distinct rows per lane group)
 constexpr int VC = 64, LDV = VC + PAD;        // v columns per FFN chunk; row stride of a v chunk buffer
 constexpr int HALO = (TH + 2) * (TW + 2);     // 180 pixels
-constexpr int DW_SLAB = 64, LDS_S = DW_SLAB + PAD;
+constexpr int DW_SLAB = 64;
+constexpr int LDS_S = DW_SLAB;                // halo slab rows unpadded: 8 lanes read one pixel's 128 bytes, the next 8 the next
+                                              // pixel's - with 128-byte rows the four 64-byte pieces of a ds_read_b128 lane group
+                                              // fall on the four bank quarters (a 144-byte stride made them collide two-way)
 
 template <int C>
 struct Cfg {
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
     const half_t* a = reinterpret_cast<const half_t*>(p.a);
     const half_t* ident = reinterpret_cast<const half_t*>(p.ident);
     [[maybe_unused]] unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
+    [[maybe_unused]] unsigned long long td[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     STAMP(ts0);
 
     // ---- weight stream of this wave's channel quarter: ring of D fragments, refilled right after use
@@ -176,9 +180,9 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
     // ---- depthwise 3x3 (zero padding) + bias -> d in bufX.  A slab goes registers -> one of two LDS halo buffers
     // (bufV region) -> taps; one barrier per slab.
     {
-        constexpr int MSTEP = NTHR / GS, ITER = M / MSTEP;
-        static_assert(M % MSTEP == 0 && ITER % 2 == 0, "depthwise pixel loop");
-        const int m0 = tid / GS;
+        // a thread owns one channel group of two vertically adjacent pixels (y, y + 1 at x): 12 tap vectors instead of 18
+        static_assert(NTHR / GS == M / 2 && TH % 2 == 0, "one pixel pair per thread and slab");
+        const int pp = tid / GS, py = 2 * (pp / TW), px = pp % TW;      // pixel pair -> rows py, py + 1, column px of the tile
 #pragma unroll
         for (int slab = 0; slab < nslab; ++slab) {
             half_t* hb = bufV + (slab & 1) * (HALO * LDS_S);
@@ -197,38 +201,31 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
 #pragma unroll
                 for (int k = 0; k < D; ++k) ring[k] = wload();
             }
+            if (slab == 0) STAMP(td[0]);
             __syncthreads();
+            if (slab < 4) STAMP(td[1 + slab]);
             const int c = slab * DW_SLAB + dcs;
-            auto taps_load = [&](int m, Vec16 (&v)[9]) __attribute__((always_inline)) {
-                const int my = m / TW, mx = m % TW;
+            Vec16 tv[4][3];
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx)
-                        v[ky * 3 + kx] = *reinterpret_cast<const Vec16*>(hb + ((my + ky) * HW_ + mx + kx) * LDS_S + dcs);
-            };
-            auto taps_apply = [&](int m, const Vec16 (&v)[9]) __attribute__((always_inline)) {
+                for (int kx = 0; kx < 3; ++kx)
+                    tv[r][kx] = *reinterpret_cast<const Vec16*>(hb + ((py + r) * HW_ + px + kx) * LDS_S + dcs);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
                 float sacc[V];
 #pragma unroll
                 for (int j = 0; j < V; ++j) sacc[j] = 0.f;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) fma_vec16<half_t>(v[t], wtap[t], sacc);
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) fma_vec16<half_t>(tv[e + ky][kx], wtap[ky * 3 + kx], sacc);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     sacc[j] = sacc[j] + bd0[j];
                     sacc[4 + j] = sacc[4 + j] + bd1[j];
                 }
-                lds_store_vec<half_t>(bufX, LDX, m, c, pack16<half_t>(sacc));
-            };
-            Vec16 ta[9], tb[9];
-            taps_load(m0, ta);
-#pragma unroll
-            for (int it = 0; it < ITER; it += 2) {
-                const int ma = m0 + it * MSTEP, mb = ma + MSTEP, mc = mb + MSTEP;
-                taps_load(mb, tb);
-                taps_apply(ma, ta);
-                if (it + 2 < ITER) taps_load(mc, ta);
-                taps_apply(mb, tb);
+                lds_store_vec<half_t>(bufX, LDX, (py + e) * TW + px, c, pack16<half_t>(sacc));
             }
         }
         __syncthreads();
@@ -242,6 +239,16 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
     auto bfrag_x = [&](int t, int s) __attribute__((always_inline)) {
         return *reinterpret_cast<const half8*>(xb + t * 32 * LDX + s * 16);
     };
+
+    // epilogue biases of this lane's rows (quads 8 g + 4 hh of each channel tile): requested ahead of the GEMM they follow
+    floatx4 ebias[NTW][4];
+    auto ebias_load = [&](const float* b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ebias[i][g] = load_f4(b + 32 * (cqw * NTW + i) + 4 * hh + 8 * g);
+    };
+    ebias_load(p.b2);
 
     // ---- GEMM2: W2 d (this wave's channel quarter x its 64 pixels)
     floatx16 acc[NTW][PTW];
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
         const int chb = 32 * (cqw * NTW + i) + 4 * hh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const floatx4 bias = load_f4(p.b2 + chb + 8 * g);
+            const floatx4 bias = ebias[i][g];
 #pragma unroll
             for (int t = 0; t < PTW; ++t) {
                 floatx4 v = {acc[i][t][4 * g], acc[i][t][4 * g + 1], acc[i][t][4 * g + 2], acc[i][t][4 * g + 3]};
@@ -415,6 +422,7 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
         step(T_{}, T_{}, T_{}, T128_OFF(OFF_EVEN), ua, ub, vA, vB, j + 3);
     }
     step(T_{}, F_{}, T_{}, T128_OFF(OFF_LAST), ub, ua, vB, vA, 0);
+    ebias_load(p.b4);
     step(T_{}, F_{}, F_{}, T128_OFF(OFF_FIN), ub, ua, vA, vB, 0);      // W4 x v(NCH-1)  (NCH - 1 is odd: its v is in buffer B = vprev)
 #undef T128_OFF
 
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
         const int chb = 32 * (cqw * NTW + i) + 4 * hh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const floatx4 bias = load_f4(p.b4 + chb + 8 * g);
+            const floatx4 bias = ebias[i][g];
 #pragma unroll
             for (int t = 0; t < PTW; ++t) {
                 const floatx4 o = lds_load_quad<half_t>(bufX, LDX, prow + 32 * t, chb + 8 * g);
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
     STAMP(ts6);
 #ifdef DCVC_DIAG
     if (p.stamps && tid == 0) {
-        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 16;
         o[0] = ts1 - ts0;   // loads + depthwise
         o[1] = ts2 - ts1;   // GEMM2
         o[2] = ts3 - ts2;   // (+b2) store, o pass
@@ -472,6 +480,12 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
         o[5] = ts6 - ts5;   // r + store
         o[6] = ts0;
         o[7] = ts6;
+        o[8] = td[0] - ts0;     // address setup + load issue + slab 0 staged
+        o[9] = td[1] - td[0];   // first barrier
+        o[10] = td[2] - td[1];  // slab 0 compute + slab 1 staging + barrier
+        o[11] = td[3] - td[2];
+        o[12] = td[4] - td[3];
+        o[13] = ts1 - td[4];    // last slab compute + barrier
     }
 #endif
     if (p.nw1 != nullptr) {

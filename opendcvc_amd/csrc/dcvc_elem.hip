@@ -603,6 +603,74 @@ int typed(int dtype, F&& launch)
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Symbol hand-off of the encoder without a copy command: the kept symbols of each part of `packed` ((sym << 8) | index,
+// low byte 0xFF = skipped) are compacted IN ORDER (the order is the bit stream) and written straight into pinned host
+// memory, part p at [p * n_per_part, + counts[p]).  Two launches: per-block counts, then prefix + scatter.
+// (reference: the boolean-mask compaction out[skip_cond] + .cpu() of cuda_inference.py:159 / entropy_models.py:48, which
+// costs a device synchronisation for the size.)
+constexpr int CB = 256;                 // threads per compaction block
+__global__ __launch_bounds__(CB) void compact_count_kernel(const int16_t* packed, int n_per_part, int seg, int* block_counts)
+{
+    const int part = blockIdx.y, b = blockIdx.x, lo = b * seg, hi = min(lo + seg, n_per_part);
+    const int16_t* src = packed + (size_t)part * n_per_part;
+    int c = 0;
+    for (int i = lo + threadIdx.x; i < hi; i += CB) c += ((src[i] & 0xFF) != 0xFF);
+    __shared__ int red[CB / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[part * gridDim.x + b] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(CB) void compact_scatter_kernel(const int16_t* packed, int n_per_part, int seg, const int* block_counts,
+                                                             int16_t* out, int* counts)
+{
+    const int part = blockIdx.y, b = blockIdx.x, nb = gridDim.x, lo = b * seg, hi = min(lo + seg, n_per_part);
+    const int16_t* src = packed + (size_t)part * n_per_part;
+    int16_t* dst = out + (size_t)part * n_per_part;
+    __shared__ int red[CB / 64];
+    __shared__ int base_sh;
+    // symbols kept by the blocks in front of this one
+    int pre = 0;
+    for (int i = threadIdx.x; i < b; i += CB) pre += block_counts[part * nb + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_down(pre, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pre;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        base_sh = red[0] + red[1] + red[2] + red[3];
+        if (b == nb - 1) counts[part] = base_sh + block_counts[part * nb + b];
+    }
+    __syncthreads();
+    int base = base_sh;
+    // the segment in rounds of CB consecutive symbols: ballot-based ranks keep the order
+    __shared__ int wsum[CB / 64];
+    for (int i0 = lo; i0 < hi; i0 += CB) {
+        const int i = i0 + threadIdx.x;
+        const int16_t v = i < hi ? src[i] : (int16_t)0xFF;
+        const bool keep = (v & 0xFF) != 0xFF;
+        const unsigned long long m = __ballot(keep);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        __syncthreads();     // (wsum of the previous round has been read)
+        if (lane == 0) wsum[w] = __popcll(m);
+        __syncthreads();
+        int off = 0;
+        for (int k = 0; k < w; ++k) off += wsum[k];
+        if (keep) dst[base + off + rank] = v;
+        base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+}
+
+__global__ void copy_f32_kernel(float* dst, const float* src, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -946,6 +1014,33 @@ int dcvc_op_bias_wsilu_depthwise_conv2d(int dtype, const void* x, const void* we
         op_bias_wsilu_dw_kernel<T><<<nblocks((int64_t)C * H * W), EB, 0, (hipStream_t)stream>>>((const T*)x, (const T*)weight, (const T*)bias, C,
                      H, W, (T*)out);
     });
+}
+
+int dcvc_compact_symbols(const int16_t* packed, int n_per_part, int n_parts, int16_t* out_host, int32_t* counts_host,
+                         int32_t* workspace, void* stream)
+{
+    DCVC_REQUIRE(packed && out_host && counts_host && workspace, "dcvc_compact_symbols: null pointer");
+    DCVC_REQUIRE(n_per_part > 0 && n_parts > 0 && n_parts <= 8, "dcvc_compact_symbols: bad sizes %d x %d", n_parts, n_per_part);
+    const int nb = DCVC_COMPACT_BLOCKS, seg = (n_per_part + nb - 1) / nb;
+    hipStream_t st = (hipStream_t)stream;
+    int16_t* out_dev = nullptr;
+    int32_t* counts_dev = nullptr;
+    DCVC_HIP(hipHostGetDevicePointer((void**)&out_dev, out_host, 0));
+    DCVC_HIP(hipHostGetDevicePointer((void**)&counts_dev, counts_host, 0));
+    hipLaunchKernelGGL(compact_count_kernel, dim3(nb, n_parts), dim3(CB), 0, st, packed, n_per_part, seg, workspace);
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3(nb, n_parts), dim3(CB), 0, st, packed, n_per_part, seg, workspace, out_dev,
+                       counts_dev);
+    DCVC_LAUNCH_CHECK();
+    return 0;
+}
+
+int dcvc_copy_f32(float* dst, const float* src, int n, void* stream)
+{
+    DCVC_REQUIRE(dst && src && n >= 0, "dcvc_copy_f32: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(copy_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+    DCVC_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // extern "C"

@@ -1053,31 +1053,27 @@ int launch_tail128(const TailParams& tp, int H, int W, hipStream_t st)
     static const bool want_stamps = getenv("DCVC_STAMPS") != nullptr;
     if (want_stamps) {
         TailParams q = tp;
-        DCVC_HIP(hipMalloc(&q.stamps, (size_t)grid * 8 * sizeof(unsigned long long)));
+        DCVC_HIP(hipMalloc(&q.stamps, (size_t)grid * 16 * sizeof(unsigned long long)));
         hipLaunchKernelGGL((t128::dcb_tail128_kernel<C>), dim3(grid), dim3(t128::NTHR), lds, st, q);
         DCVC_HIP(hipStreamSynchronize(st));
-        std::vector<unsigned long long> hs((size_t)grid * 8);
+        std::vector<unsigned long long> hs((size_t)grid * 16);
         DCVC_HIP(hipMemcpy(hs.data(), q.stamps, hs.size() * 8, hipMemcpyDeviceToHost));
         (void)hipFree(q.stamps);
         static int printed = 0;
         if (printed++ % 16 == 15) {
-            const char* names[6] = {"fill+dw", "gemm2", "o_pass", "u0", "ffn", "r+store"};
+            const char* names[14] = {"loads+dw", "gemm2", "o_pass", "u0", "ffn", "r+store", "", "", "dw:issue+stage0", "barrier0", "slab0", "slab1", "slab2", "slab3"};
             fprintf(stderr, "[t128 stamps C=%d grid=%d]", C, grid);
-            for (int k = 0; k < 6; ++k) {
+            for (int k = 0; k < 14; ++k) {
+                if (k == 6 || k == 7) continue;
                 std::vector<unsigned long long> v(grid);
-                for (int b = 0; b < grid; ++b) v[b] = hs[(size_t)b * 8 + k];
+                for (int b = 0; b < grid; ++b) v[b] = hs[(size_t)b * 16 + k];
                 std::sort(v.begin(), v.end());
                 fprintf(stderr, " %s=%llu", names[k], v[grid / 2]);
             }
-            unsigned long long t0 = ~0ull, t1 = 0;
             std::vector<unsigned long long> du(grid);
-            for (int b = 0; b < grid; ++b) {
-                t0 = std::min(t0, hs[(size_t)b * 8 + 6]);
-                t1 = std::max(t1, hs[(size_t)b * 8 + 7]);
-                du[b] = hs[(size_t)b * 8 + 7] - hs[(size_t)b * 8 + 6];
-            }
+            for (int b = 0; b < grid; ++b) du[b] = hs[(size_t)b * 16 + 7] - hs[(size_t)b * 16 + 6];
             std::sort(du.begin(), du.end());
-            fprintf(stderr, " | wg total min/med/max %llu %llu %llu span %llu\n", du[0], du[grid / 2], du[grid - 1], t1 - t0);
+            fprintf(stderr, " | wg total min/med/max %llu %llu %llu\n", du[0], du[grid / 2], du[grid - 1]);
         }
         return 0;
     }

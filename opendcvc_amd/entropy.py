@@ -101,6 +101,16 @@ class PinnedBuffer:
         if not self.ptr:
             raise DcvcError("pinned host allocation failed")
         self.u8 = np.ctypeslib.as_array(ctypes.cast(self.ptr, ctypes.POINTER(ctypes.c_uint8)), (self.nbytes,))
+        self._dptr = None
+
+    @property
+    def dptr(self):
+        """device address of the buffer (kernels write the coder's input in place: no copy command)"""
+        if self._dptr is None:
+            self._dptr = _lib.lib().dcvc_host_device_ptr(ctypes.c_void_p(self.ptr))
+            if not self._dptr:
+                raise DcvcError("pinned buffer has no device address")
+        return self._dptr
 
     def view(self, dtype, count):
         return self.u8[:count * np.dtype(dtype).itemsize].view(dtype)

@@ -274,7 +274,10 @@ class CompressionModel(tnn.Module):
         return dtype, device
 
     def _stage_q(self, qp):
-        self._q_row.copy_(self._q_cat[qp], non_blocking=True)
+        """the frame's rows of the quantisation tables -> fixed addresses (what the captured runs read): one small kernel
+        (a runtime copy command costs ~40 us of stream time, profiles/r02_launches_per_pair.txt)"""
+        row = self._q_cat[qp]
+        check(_lib.lib().dcvc_copy_f32(L._p(self._q_row), L._p(row), row.numel(), self._stream()), "copy_f32")
         return self._qv
 
     def _buffer(self, name, shape, dtype, device):
@@ -284,6 +287,15 @@ class CompressionModel(tnn.Module):
         if b is None:
             b = self._persist[key] = torch.zeros(shape, dtype=dtype, device=device)
         return b
+
+    def _picture_out(self, head):
+        """PixelShuffle(8) + clamp of the last conv's output into one of TWO alternating picture buffers, launched outside
+        the captured run (whose own output buffer would be overwritten by the next frame): the returned picture stays
+        valid until the second following frame has been produced - no copy (the reference returns a fresh tensor)."""
+        H, W, _, _ = L._geom(head)
+        self._pic_parity = getattr(self, "_pic_parity", 0) ^ 1
+        buf = self._buffer(f"picture_{self._pic_parity}", (1, 3, H * 8, W * 8), head.dtype, head.device)
+        return self._shuffle8_clamp(head, out=buf)
 
     def _thres(self):
         return -1.0 if self.force_zero_thres is None else float(self.force_zero_thres)
@@ -310,9 +322,10 @@ class CompressionModel(tnn.Module):
               "unshuffle8")
         return out
 
-    def _shuffle8_clamp(self, x, bias=None):
+    def _shuffle8_clamp(self, x, bias=None, out=None):
         H, W, C, ld = L._geom(x)
-        out = torch.empty((1, 3, H * 8, W * 8), dtype=x.dtype, device=x.device)
+        if out is None:
+            out = torch.empty((1, 3, H * 8, W * 8), dtype=x.dtype, device=x.device)
         check(_lib.lib().dcvc_shuffle8_clamp(L.dtype_code(x.dtype), L._p(x), ld, L._p(bias), 3, H, W, 1, L._p(out),
                                              self._stream()), "shuffle8_clamp")
         return out
@@ -348,6 +361,26 @@ class CompressionModel(tnn.Module):
         buf = self.entropy_coder.pinned(key, t.numel() * t.element_size())
         check(_lib.lib().dcvc_memcpy_d2h(ctypes.c_void_p(buf.ptr), L._p(t), t.numel() * t.element_size(), self._stream()), "d2h")
         return buf
+
+    def _symbols_to_host(self, key, z8, packed):
+        """Encoder hand-off without a copy command: z (int8) and the KEPT y symbols of each part of `packed`, compacted in
+        order on the device, are written by kernels straight into pinned host buffers (dcvc_compact_symbols).  Returns
+        (z buffer, symbol buffer, counts buffer); valid for the host once the stream has passed this point."""
+        lib = _lib.lib()
+        ec = self.entropy_coder
+        parts, nsym = packed.shape
+        nz = z8.numel()
+        hz = ec.pinned(key + "_z", (nz + 3) // 4 * 4)
+        hp = ec.pinned(key + "_sym", parts * nsym * 2)
+        hc = ec.pinned(key + "_cnt", 4 * parts)
+        ws = self._buffer("compact_ws", (256 * parts,), torch.int32, packed.device)
+        if nz % 4 == 0:
+            check(lib.dcvc_copy_f32(ctypes.c_void_p(hz.dptr), L._p(z8), nz // 4, self._stream()), "z to host")
+        else:
+            check(lib.dcvc_memcpy_d2h(ctypes.c_void_p(hz.ptr), L._p(z8), nz, self._stream()), "d2h")
+        check(lib.dcvc_compact_symbols(L._p(packed), nsym, parts, ctypes.c_void_p(hp.ptr), ctypes.c_void_p(hc.ptr), L._p(ws),
+                                       self._stream()), "compact_symbols")
+        return hz, hp, hc
 
     def _prior_enc_step(self, groups, step, q_mode, y, qsrc, scales, means, yhat, packed):
         H, W, C, ldy = L._geom(y)
@@ -524,10 +557,14 @@ class DMC(CompressionModel):
         n = self._layers
         return L.dcb_chain(n["dec_conv1"], n["dec_up"](y_hat), ctx, then_conv=n["dec_conv2"], conv_quant=q_decoder, out=out)
 
-    def _recon(self, feature, q_recon):
+    def _recon_head(self, feature, q_recon):
+        """recon_generation_net up to its last conv (video_model.py:151-163); _picture_out() makes the picture of it"""
         n = self._layers
         o = L.dcb_chain(n["recon"], feature, quant=q_recon)
-        return self._shuffle8_clamp(n["recon_head"](o))
+        return n["recon_head"](o)
+
+    def _recon(self, feature, q_recon):
+        return self._picture_out(self._recon_head(feature, q_recon))
 
     # the same network in two halves (deferred decoder output: each half fills one host-decoding gap of the next frame)
     def _recon_first(self, feature):
@@ -535,7 +572,7 @@ class DMC(CompressionModel):
 
     def _recon_second(self, mid, q_recon):
         n = self._layers
-        return self._shuffle8_clamp(n["recon_head"](L.dcb_chain(n["recon"][2:], mid, quant=q_recon)))
+        return n["recon_head"](L.dcb_chain(n["recon"][2:], mid, quant=q_recon))      # (the picture: _picture_out)
 
     def _pending_half(self, which):
         """launches one half of the pending reconstruction (no-op when nothing is pending / already done)"""
@@ -546,8 +583,8 @@ class DMC(CompressionModel):
             pd["mid"] = self._graphs.run(("dec_ra",) + pd["key"], lambda: self._recon_first(pd["feature"]))
         elif which == 1 and pd["mid"] is not None and pd["x_hat"] is None:
             mid, qrec = pd["mid"], pd["q_recon"]
-            x = self._graphs.run(("dec_rb",) + pd["key"], lambda: self._recon_second(mid, qrec))
-            pd["x_hat"] = x.clone() if self._graphs.enabled else x
+            head = self._graphs.run(("dec_rb",) + pd["key"], lambda: self._recon_second(mid, qrec))
+            pd["x_hat"] = self._picture_out(head)
 
     def finish_output(self):
         """Deferred decoder output: completes and returns the reconstruction of the last decompress(...,
@@ -581,14 +618,14 @@ class DMC(CompressionModel):
 
     def _code_symbols(self, job):
         """host: entropy-codes one frame's symbols (waits for their copy to the pinned staging first)"""
-        ready, hz, hp, nz, nsym, zhw, qp = job
+        ready, hz, hp, hc, nz, nsym, zhw, qp = job
         ready.synchronize()
         ec = self.entropy_coder
         ec.reset()
         ec.encode_z(hz.view(np.int8, nz), self._z_group, qp * self.z_channel, zhw)
-        ps = hp.view(np.int16, 2 * nsym)
-        ec.encode_y(ps[:nsym], self._g_group, borrowed=True)     # pinned staging buffer, untouched until
-        ec.encode_y(ps[nsym:], self._g_group, borrowed=True)     # get_encoded_stream() below
+        ps, kept = hp.view(np.int16, 2 * nsym), hc.view(np.int32, 2)
+        ec.encode_y(ps[:kept[0]], self._g_group, borrowed=True)                 # pinned staging buffer, untouched until
+        ec.encode_y(ps[nsym:nsym + kept[1]], self._g_group, borrowed=True)     # get_encoded_stream() below
         ec.flush()
         return ec.get_encoded_stream()
 
@@ -644,12 +681,11 @@ class DMC(CompressionModel):
 
         y_hat, ctx, z8, packed, nz, nsym, (zh, zw) = self._graphs.run(
             ("enc_front_ahead" if ahead is not None else "enc_front",) + key, front)
-        # symbols -> pinned staging (outside the captured run: two staging sets alternate, so that the host may still
-        # be coding the previous frame out of the other one while this copy lands)
+        # symbols -> pinned staging, compacted, by kernels (outside the captured run: two staging sets alternate, so that
+        # the host may still be coding the previous frame out of the other one while these writes land)
         par = self._stream_parity
         self._stream_parity ^= 1
-        hz = self._d2h(f"z8_{par}", z8)
-        hp = self._d2h(f"packed_{par}", packed)
+        hz, hp, hc = self._symbols_to_host(f"enc{par}", z8, packed)
         ready = torch.cuda.Event()
         ready.record()
         # the decoder keeps the GPU busy while the host codes
@@ -664,7 +700,7 @@ class DMC(CompressionModel):
 
         # host entropy coding: the previous frame's deferred symbols first (its staging set is reused two frames on)
         prev = self.finish_stream()
-        job = (ready, hz, hp, nz, nsym, zh * zw, qp)
+        job = (ready, hz, hp, hc, nz, nsym, zh * zw, qp)
         # no device synchronisation here (the reference has none either): the tail of the decoder stays in
         # flight on this stream and overlaps the caller's next host work; callers that time a frame sync.
         self.add_ref_frame(fbuf, None)
@@ -740,15 +776,14 @@ class DMC(CompressionModel):
             self._symbols_to_device(sym1, n_half, 2, 1, sp[:, :, C:], y_hat, yh, yw, C, out=y_fin)
             self._prior_finish(0, y_fin, params[:, :, :C])
             feature = self._decoder(y_fin, ctx, q["q_decoder"], out=fbuf)
-            return None if defer_output else self._recon(feature, q["q_recon"])
+            return None if defer_output else self._recon_head(feature, q["q_recon"])
 
         x_prev = None
         if prev is not None:              # both halves of the previous frame's reconstruction are in flight by now
             x_prev = prev["x_hat"]
             self._pending = None
-        x_hat = self._graphs.run(("dec_4d" if defer_output else "dec_4",) + key, after_step1)
-        if x_hat is not None and self._graphs.enabled:
-            x_hat = x_hat.clone()          # the captured run reuses its output buffer on the next frame
+        head = self._graphs.run(("dec_4d" if defer_output else "dec_4",) + key, after_step1)
+        x_hat = None if head is None else self._picture_out(head)
         self.add_ref_frame(fbuf, x_hat)
         if defer_output:
             qrec = self._buffer("q_recon_pending", q["q_recon"].shape, torch.float32, device)
@@ -756,6 +791,10 @@ class DMC(CompressionModel):
             self._pending = dict(key=(sps["height"], sps["width"]), feature=fbuf, q_recon=qrec, mid=None, x_hat=None)
             return {"x_hat": None, "x_hat_prev": x_prev if x_prev is not None else forced}
         return {"x_hat": x_hat} if forced is None else {"x_hat": x_hat, "x_hat_prev": forced}
+
+
+DMC.encode_one_frame = DMC.compress          # the names BASELINE.json's north_star uses for the per-frame API (the reference
+DMC.decode_one_frame = DMC.decompress        # itself has only compress / decompress: SURVEY.md section 0-1)
 
 
 # =============================================================================== DMCI (I frames)
@@ -795,7 +834,7 @@ class DMCI(CompressionModel):
     def _dec(self, y_hat, q):
         n = self._layers
         o = L.dcb_chain(n["dec_1"], n["dec_up"](y_hat), quant=q)
-        return self._shuffle8_clamp(n["dec_2"](o))
+        return n["dec_2"](o)             # (the picture: _picture_out)
 
     def _prior_params(self, z_hat, yh, yw):
         n = self._layers
@@ -835,22 +874,21 @@ class DMCI(CompressionModel):
                 sp = self._spatial_prior(y_hat, common, step)
                 self._prior_enc_step(4, step, 1, y, params, sp[:, :, :C], sp[:, :, C:], y_hat, packed[step])
             self._prior_finish(1, y_hat, params)
-            return y_hat, self._d2h("z8", z8), self._d2h("packed", packed), z8.numel(), nsym, (z.shape[0], z.shape[1])
+            return y_hat, z8, packed, z8.numel(), nsym, (z.shape[0], z.shape[1])
 
-        y_hat, hz, hp, nz, nsym, (zh, zw) = self._graphs.run(("ienc_front",) + key, front)
+        y_hat, z8, packed, nz, nsym, (zh, zw) = self._graphs.run(("ienc_front",) + key, front)
+        hz, hp, hc = self._symbols_to_host("ienc", z8, packed)
         ready = torch.cuda.Event()
         ready.record()
-        x_hat = self._graphs.run(("ienc_back",) + key, lambda: self._dec(y_hat, q["q_scale_dec"]))
-        if self._graphs.enabled:
-            x_hat = x_hat.clone()          # the captured run reuses its output buffer on the next frame
+        x_hat = self._picture_out(self._graphs.run(("ienc_back",) + key, lambda: self._dec(y_hat, q["q_scale_dec"])))
 
         ready.synchronize()
         ec = self.entropy_coder
         ec.reset()
         ec.encode_z(hz.view(np.int8, nz), self._z_group, qp * self.z_channel, zh * zw)
-        ps = hp.view(np.int16, 4 * nsym)
+        ps, kept = hp.view(np.int16, 4 * nsym), hc.view(np.int32, 4)
         for k in range(4):
-            ec.encode_y(ps[k * nsym:(k + 1) * nsym], self._g_group, borrowed=True)
+            ec.encode_y(ps[k * nsym:k * nsym + kept[k]], self._g_group, borrowed=True)
         ec.flush()
         bit_stream = ec.get_encoded_stream()
         return {"bit_stream": bit_stream, "x_hat": x_hat}
@@ -906,6 +944,8 @@ class DMCI(CompressionModel):
             else:
                 y_prev, sp, idx = res
                 means = sp[:, :, C:]
-        if self._graphs.enabled:
-            x_hat = x_hat.clone()
-        return {"x_hat": x_hat}
+        return {"x_hat": self._picture_out(x_hat)}
+
+
+DMCI.encode_one_frame = DMCI.compress
+DMCI.decode_one_frame = DMCI.decompress

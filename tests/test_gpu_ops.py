@@ -162,3 +162,29 @@ def test_unshuffle8_shuffle8_layout_kernels(dtype, hw):
     ref = (out.float() + bias).to(dtype).float().clamp(0, 1).to(dtype)
     ref = torch.nn.functional.pixel_shuffle(ref.permute(2, 0, 1)[None], 8)
     assert torch.equal(back, ref)
+
+
+@pytest.mark.parametrize("parts,n", [(2, 5000), (4, 777), (2, 522240), (1, 1)])
+def test_compact_symbols_writes_kept_entries_in_order_to_pinned_memory(parts, n):
+    """dcvc_compact_symbols (the encoder's symbol hand-off without a copy command; replaces the reference's boolean-mask
+    compaction + .cpu(), cuda_inference.py:159): kept entries of every part in order, counts, nothing else touched."""
+    import ctypes
+    from opendcvc_amd import _lib, entropy, nn
+    rng = np.random.default_rng(parts * 1000 + n)
+    a = rng.integers(-32768, 32767, (parts, n), dtype=np.int16)
+    skip = rng.random((parts, n)) < 0.7
+    a = np.where(skip, (a & ~0xFF) | 0xFF, np.where((a & 0xFF) == 0xFF, a & ~1, a)).astype(np.int16)
+    dev = torch.from_numpy(a).cuda()
+    out, cnt = entropy.PinnedBuffer(parts * n * 2), entropy.PinnedBuffer(4 * parts)
+    out.u8[:] = 0xAB
+    ws = torch.zeros(256 * parts, dtype=torch.int32, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.lib().dcvc_compact_symbols(nn._p(dev), n, parts, ctypes.c_void_p(out.ptr), ctypes.c_void_p(cnt.ptr),
+                                               nn._p(ws), st), "compact")
+    torch.cuda.synchronize()
+    got, kept = out.view(np.int16, parts * n).reshape(parts, n), cnt.view(np.int32, parts)
+    for p in range(parts):
+        want = a[p][~skip[p]]
+        assert kept[p] == want.size
+        assert np.array_equal(got[p, :want.size], want)
+        assert np.all(got[p, want.size:].view(np.uint8) == 0xAB)
