@@ -36,22 +36,51 @@ def gpu_local_cpus(sysfs="/sys/class/drm"):
     return [c for _, c in sorted(gpus)]
 
 
-def rank_cpus(local_rank, local_world, allowed=None, gpu_cpus=None):
+def cgroup_cpu_quota(path="/sys/fs/cgroup/cpu.max"):
+    """CPUs' worth of time the cgroup grants this process (cgroup v2 cpu.max = quota / period), or None without a limit.
+    A GPU box shows the host's 256 hardware threads in the affinity mask and grants a 16-CPU share."""
+    try:
+        quota, period = open(path).read().split()[:2]
+        if quota != "max":
+            return max(1, int(round(int(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def cpus_granted(local_world, allowed=None, quota="auto"):
+    """CPUs one of `local_world` ranks on this node can count on: its share of the affinity mask, cut down to its share
+    of the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0) if allowed is None else allowed)
+    q = cgroup_cpu_quota() if quota == "auto" else quota
+    if q is not None:
+        n = min(n, q)
+    return max(1, n // max(1, local_world))
+
+
+def rank_cpus(local_rank, local_world, allowed=None, gpu_cpus=None, quota="auto"):
     """The CPU set rank `local_rank` of `local_world` ranks on this node should run on: the allowed CPUs local to its
     GPU's NUMA node, divided evenly between the ranks whose GPUs share that node; without topology information (or
     when the local CPUs are not among the allowed ones) a contiguous 1/local_world slice of the allowed CPUs."""
     allowed = sorted(os.sched_getaffinity(0) if allowed is None else allowed)
-    gpu_cpus = gpu_local_cpus() if gpu_cpus is None else gpu_cpus
+    if gpu_cpus is None:
+        # sysfs lists the GPUs in PCI order = the HIP device order only while no *_VISIBLE_DEVICES variable remaps it
+        remapped = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+        gpu_cpus = [] if remapped else gpu_local_cpus()
+    # A cgroup CPU quota below the mask (16 CPUs of time on a 256-thread mask): a rank keeps its threads on as many CPUs
+    # of its slice as its share of the quota is worth - spreading them over the whole slice buys no CPU time.
+    keep = cpus_granted(local_world, allowed, quota)
+    part = None
     if len(gpu_cpus) >= local_world and all(gpu_cpus[r] & set(allowed) for r in range(local_world)):
         mine = sorted(gpu_cpus[local_rank] & set(allowed))
         peers = [r for r in range(local_world) if gpu_cpus[r] == gpu_cpus[local_rank]]
         k, n = peers.index(local_rank), len(peers)
         part = mine[k * len(mine) // n:(k + 1) * len(mine) // n]
-        if part:
-            return part
-    n = len(allowed)
-    part = allowed[local_rank * n // local_world:(local_rank + 1) * n // local_world]
-    return part or allowed
+    if not part:
+        n = len(allowed)
+        part = allowed[local_rank * n // local_world:(local_rank + 1) * n // local_world]
+    part = part or allowed
+    return part[:max(1, keep)] if len(part) > keep else part
 
 
 def pin_rank_threads(local_rank, local_world):

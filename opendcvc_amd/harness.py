@@ -8,12 +8,19 @@ Restates (no code shared) the behaviour of the reference harness:
   test_video.py:448-463   the qp points of a sweep
   src/utils/metrics.py:81-96   calc_psnr
   src/utils/common.py:63-177   generate_log_json
-Dataset manifests, PNG sources, MS-SSIM and the multi-process sequence pool are out of scope (SURVEY section 2,
-rows 11-15); the codec calls are the drop-in DMCI / DMC of opendcvc_amd.models.
+  test_video.py:381-442,472-532   the job fan-out: a JSON dataset manifest, one job per (sequence, rate point), a pool
+                          of spawned worker processes (-w), worker n on GPU n % gpu_num, one merged JSON log
+  src/utils/common.py:49-60      dump_json (floats with six digits)
+PNG sources and MS-SSIM are out of scope; the codec calls are the drop-in DMCI / DMC of
+opendcvc_amd.models.
+
+    python -m opendcvc_amd.harness --test-config cfg.json -w 16 --gpus 8 --output-path out.json     # configs[4]
 """
+import importlib
 import io
 import json
 import math
+import os
 import time
 
 import numpy as np
@@ -215,16 +222,169 @@ def run_sweep(make_nets, src_path, width, height, frame_num, rate_num=4, qp_i=No
     return out
 
 
+# ---------------------------------------------------------------------------------- job fan-out (test_video.py main)
+def dump_json(obj, fp, float_digits=6, indent=2):
+    """The reference's log writer (common.py:49-60): json.dump with every float printed with `float_digits` digits."""
+    enc = json.JSONEncoder(indent=indent)
+    it = json.encoder._make_iterencode({}, enc.default, json.encoder.encode_basestring_ascii, " " * indent,
+                                       lambda o: format(o, ".%df" % float_digits), enc.key_separator, enc.item_separator,
+                                       enc.sort_keys, enc.skipkeys, False)
+    for chunk in it(obj, 0):
+        fp.write(chunk)
+
+
+def jobs_from_config(config, opts):
+    """One job per (dataset, sequence, rate point), in the reference's submission order (test_video.py:472-510).
+    config: the parsed dataset manifest (dataset_config_example_yuv420.json); opts: see run_config()."""
+    qi = list(opts["qp_i"]) if opts.get("qp_i") else sweep_qps(opts.get("rate_num", 4))
+    qp = list(opts["qp_p"]) if opts.get("qp_p") else qi
+    assert len(qi) == len(qp)
+    root = opts.get("force_root_path") or config["root_path"]
+    jobs = []
+    for ds_name, ds in config["test_classes"].items():
+        if ds["test"] == 0:
+            continue
+        if ds["src_type"] != "yuv420":
+            raise ValueError(f"{ds_name}: only planar 8-bit YUV 4:2:0 sources are supported (src_type {ds['src_type']})")
+        for seq, info in ds["sequences"].items():
+            for rate_idx, (q, qq) in enumerate(zip(qi, qp)):
+                ip = info["intra_period"]
+                if opts.get("force_intra_period", 0) > 0:
+                    ip = opts["force_intra_period"]
+                fn = opts["force_frame_num"] if opts.get("force_frame_num", 0) > 0 else info["frames"]
+                jobs.append(dict(ds_name=ds_name, seq=seq, rate_idx=rate_idx, qp_i=q, qp_p=qq,
+                                 src_path=os.path.join(root, ds["base_path"], seq), src_width=info["width"],
+                                 src_height=info["height"], frame_num=fn, intra_period=ip,
+                                 reset_interval=opts.get("reset_interval", 32)))
+    return jobs
+
+
+def merge_results(config, results):
+    """{dataset: {sequence: {"000": result, "001": ...}}} (test_video.py:517-528)"""
+    log = {}
+    for ds_name, ds in config["test_classes"].items():
+        if ds["test"] == 0:
+            continue
+        log[ds_name] = {seq: {} for seq in ds["sequences"]}
+    for res in results:
+        log[res["ds_name"]][res["seq"]][f"{res['rate_idx']:03d}"] = res
+    return log
+
+
+_WORKER = {}
+
+
+def worker_gpu(process_name, gpu_num):
+    """test_video.py:384-388: worker process n (the number at the end of its multiprocessing name) codes on GPU
+    n % gpu_num; -1 without GPUs."""
+    idx = int(process_name[process_name.rfind("-") + 1:])
+    return idx % gpu_num if gpu_num > 0 else -1
+
+
+def _init_worker(opts, gpu_num):
+    """Runs once in every spawned worker (test_video.py:381-414): picks the GPU, pins the process, loads both models."""
+    import multiprocessing
+    gpu = worker_gpu(multiprocessing.current_process().name, gpu_num)
+    if gpu >= 0:
+        ids = opts.get("gpu_ids")
+        os.environ["HIP_VISIBLE_DEVICES"] = str(ids[gpu] if ids else gpu)     # before the first GPU call of the process
+    workers_here = max(1, opts.get("workers", 1))
+    try:      # every worker gets its share of the CPUs the cgroup grants (two codec threads + the rANS workers each)
+        from . import dist
+        os.sched_setaffinity(0, dist.rank_cpus((int(multiprocessing.current_process().name.rsplit("-", 1)[1]) - 1) % workers_here,
+                                               workers_here, gpu_cpus=[]))
+    except (OSError, ValueError, ImportError):
+        pass
+    mod, fn = opts.get("codec", "opendcvc_amd.harness:default_nets").split(":")
+    _WORKER["gpu"] = gpu
+    _WORKER["nets"] = getattr(importlib.import_module(mod), fn)(opts)
+    mod, fn = opts.get("runner", "opendcvc_amd.harness:run_job").split(":")
+    _WORKER["run"] = getattr(importlib.import_module(mod), fn)
+    _WORKER["opts"] = opts
+
+
+def default_nets(opts):
+    """(DMCI, DMC) ready to code: checkpoints if given (reference keys), else the synthetic weights; on cuda:0 of the
+    worker (its HIP_VISIBLE_DEVICES names one GPU); fp16 like the reference harness unless opts['fp32']."""
+    import torch
+    from . import weights
+    from .models import DMC, DMCI
+    torch.set_num_threads(1)          # src/utils/common.py:23
+    nets = []
+    for cls, name, path in ((DMCI, "dmci", opts.get("model_i")), (DMC, "dmc", opts.get("model_p"))):
+        m = cls()
+        if path:
+            ck = torch.load(path, map_location="cpu", weights_only=True)
+            ck = ck.get("state_dict", ck)
+            ck = ck.get("net", ck)
+            m.load_state_dict({k[7:] if k.startswith("module.") else k: v for k, v in ck.items()})
+        else:
+            m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in
+                               weights.make_state_dict(name, 1234).items()})
+        m.to("cuda:0").eval()
+        m.update(opts.get("force_zero_thres", 0.12))
+        if not opts.get("fp32"):
+            m.half()
+        nets.append(m)
+    return nets
+
+
+def run_job(nets, job, opts):
+    """one (sequence, rate point) on this worker's GPU -> the reference-schema log of the point"""
+    bin_path = None
+    if opts.get("stream_path"):
+        folder = os.path.join(opts["stream_path"], job["ds_name"])
+        os.makedirs(folder, exist_ok=True)
+        bin_path = os.path.join(folder, f"{job['seq']}_q{job['qp_i']}.bin")         # test_video.py:364-367
+    return run_one_point(nets[0], nets[1], job["src_path"], job["src_width"], job["src_height"], job["frame_num"],
+                         job["qp_i"], job["qp_p"], intra_period=job["intra_period"], reset_interval=job["reset_interval"],
+                         bin_path=bin_path, verbose=opts.get("verbose", 0), verbose_json=opts.get("verbose_json", False),
+                         device="cuda:0")
+
+
+def _worker(job):
+    res = _WORKER["run"](_WORKER["nets"], job, _WORKER["opts"])
+    res["ds_name"], res["seq"], res["rate_idx"] = job["ds_name"], job["seq"], job["rate_idx"]      # test_video.py:371-376
+    res["qp_i"], res["qp_p"] = job["qp_i"], job["qp_p"]
+    if _WORKER["opts"].get("record_gpu"):
+        res["gpu"] = _WORKER["gpu"]
+    return res
+
+
+def run_config(config, opts, workers=1, gpus=1):
+    """The reference's main loop (test_video.py:417-532): every (sequence, rate point) of the manifest as a job on a pool
+    of `workers` spawned processes, worker n on GPU n % gpus (so -w may exceed the GPU count: two streams per GPU
+    give ~16 % more frames/s on an MI355X, profiles/r02_multistream.txt); returns the merged log."""
+    import concurrent.futures
+    import multiprocessing
+    jobs = jobs_from_config(config, opts)
+    opts = dict(opts, workers=workers)
+    ctx = multiprocessing.get_context("spawn")
+    with concurrent.futures.ProcessPoolExecutor(max_workers=workers, mp_context=ctx, initializer=_init_worker,
+                                                initargs=(opts, gpus)) as pool:
+        results = [f.result() for f in [pool.submit(_worker, j) for j in jobs]]
+    return merge_results(config, results)
+
+
 def main(argv=None):
     import argparse
     import torch
     from . import weights
     from .models import DMC, DMCI
     ap = argparse.ArgumentParser(description="DCVC-RT rate points of one YUV 4:2:0 sequence on the MI355X path")
-    ap.add_argument("--src", required=True)
-    ap.add_argument("--width", type=int, required=True)
-    ap.add_argument("--height", type=int, required=True)
-    ap.add_argument("--frames", type=int, required=True)
+    ap.add_argument("--test-config", help="JSON dataset manifest (reference: dataset_config_example_yuv420.json): every "
+                    "sequence x rate point becomes a job on the worker pool (reference: test_video.py --test_config)")
+    ap.add_argument("-w", "--worker", type=int, default=1, help="worker processes (may exceed --gpus)")
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs to spread the workers over (default: all visible)")
+    ap.add_argument("--force-root-path")
+    ap.add_argument("--force-frame-num", type=int, default=-1)
+    ap.add_argument("--force-intra-period", type=int, default=-1)
+    ap.add_argument("--stream-path", help="write every point's container to <stream-path>/<dataset>/<sequence>_q<qp>.bin")
+    ap.add_argument("--output-path", help="merged JSON log of the manifest run")
+    ap.add_argument("--src")
+    ap.add_argument("--width", type=int)
+    ap.add_argument("--height", type=int)
+    ap.add_argument("--frames", type=int)
     ap.add_argument("--rate-num", type=int, default=4)
     ap.add_argument("--qp-i", type=int, nargs="*")
     ap.add_argument("--qp-p", type=int, nargs="*")
@@ -239,6 +399,30 @@ def main(argv=None):
     ap.add_argument("--verbose", type=int, default=1)
     ap.add_argument("--verbose-json", action="store_true", help="per-frame lists in the log (reference --verbose_json)")
     args = ap.parse_args(argv)
+    if args.test_config:
+        with open(args.test_config) as f:
+            config = json.load(f)
+        gpus = args.gpus if args.gpus is not None else torch.cuda.device_count()
+        opts = dict(rate_num=args.rate_num, qp_i=args.qp_i, qp_p=args.qp_p, force_root_path=args.force_root_path,
+                    force_frame_num=args.force_frame_num, force_intra_period=args.force_intra_period,
+                    reset_interval=args.reset_interval, model_i=args.model_i, model_p=args.model_p,
+                    force_zero_thres=args.force_zero_thres, fp32=args.fp32, stream_path=args.stream_path,
+                    verbose=args.verbose, verbose_json=args.verbose_json)
+        t0 = time.time()
+        log = run_config(config, opts, workers=args.worker, gpus=gpus)
+        out_path = args.output_path or args.out
+        if out_path:
+            os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+            with open(out_path, "w") as f:
+                dump_json(log, f, float_digits=6, indent=2)
+        else:
+            import sys
+            dump_json(log, sys.stdout, float_digits=6, indent=2)
+        print(f"\nTest finished: {sum(len(v) for d in log.values() for v in d.values())} points, "
+              f"{(time.time() - t0) / 60:.1f} min")
+        return
+    if not (args.src and args.width and args.height and args.frames):
+        ap.error("either --test-config or --src/--width/--height/--frames")
 
     def make_nets():
         nets = []

@@ -97,20 +97,36 @@ def test_bench_control_flow_world2():
     assert e0 == e1 and e0 >= 0.002 * 20 * 0.9                     # MAX over ranks: the slower rank's 2 ms per frame
     assert a0 == a1 == (22 - 5) % 32                               # 20 timed frames start at frame 22: the I frame (32) is inside
     assert c0 == c1 == [(5 + a0, False), (20, True)]              # exactly K timed steps after warm-up + alignment
-    assert cpu0 and cpu1 and not (set(cpu0) & set(cpu1))           # the two ranks were given disjoint cores
+    assert cpu0 and cpu1
+    if len(os.sched_getaffinity(0)) >= 2:                          # (a one-CPU mask leaves nothing to split)
+        assert not (set(cpu0) & set(cpu1))                         # the two ranks were given disjoint cores
 
 
 def test_rank_cpu_partition():
     allowed = list(range(64))
     # no topology: contiguous slices
-    parts = [dist_utils.rank_cpus(r, 8, allowed, gpu_cpus=[]) for r in range(8)]
+    parts = [dist_utils.rank_cpus(r, 8, allowed, gpu_cpus=[], quota=None) for r in range(8)]
     assert sorted(sum(parts, [])) == allowed and all(len(p) == 8 for p in parts)
     # two NUMA nodes with four GPUs each: every rank stays on its GPU's node, ranks of a node split it
     node = [set(range(0, 32))] * 4 + [set(range(32, 64))] * 4
-    parts = [dist_utils.rank_cpus(r, 8, allowed, gpu_cpus=node) for r in range(8)]
+    parts = [dist_utils.rank_cpus(r, 8, allowed, gpu_cpus=node, quota=None) for r in range(8)]
     assert all(set(parts[r]) <= node[r] and len(parts[r]) == 8 for r in range(8))
     assert sorted(sum(parts, [])) == allowed
     # local CPUs outside the allowed set (container cpuset): fall back to slices of what is allowed
-    parts = [dist_utils.rank_cpus(r, 2, list(range(8)), gpu_cpus=[set(range(100, 110))] * 2) for r in range(2)]
+    parts = [dist_utils.rank_cpus(r, 2, list(range(8)), gpu_cpus=[set(range(100, 110))] * 2, quota=None) for r in range(2)]
     assert parts == [[0, 1, 2, 3], [4, 5, 6, 7]]
-    assert dist_utils.rank_cpus(0, 1, allowed, gpu_cpus=[]) == allowed
+    assert dist_utils.rank_cpus(0, 1, allowed, gpu_cpus=[], quota=None) == allowed
+    # a cgroup CPU quota below the mask (the GPU boxes: 256 hardware threads visible, 16 CPUs granted): a rank keeps its
+    # threads on its share of the quota inside its slice
+    parts = [dist_utils.rank_cpus(r, 8, list(range(256)), gpu_cpus=[], quota=16) for r in range(8)]
+    assert all(len(p) == 2 for p in parts) and len({c for p in parts for c in p}) == 16
+    assert [p[0] for p in parts] == [32 * r for r in range(8)]
+    assert dist_utils.cpus_granted(8, list(range(256)), quota=16) == 2 and dist_utils.cpus_granted(1, list(range(8)), quota=None) == 8
+
+
+def test_visible_devices_remap_disables_the_sysfs_order(monkeypatch):
+    """HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES remap device indices: sysfs PCI order is then not the HIP order, and
+    rank_cpus falls back to plain slices instead of pinning ranks to another GPU's NUMA node."""
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "3,1")
+    monkeypatch.setattr(dist_utils, "gpu_local_cpus", lambda *a, **k: (_ for _ in ()).throw(AssertionError("sysfs order used")))
+    assert dist_utils.rank_cpus(1, 2, list(range(8)), quota=None) == [4, 5, 6, 7]

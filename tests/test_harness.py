@@ -145,3 +145,38 @@ def test_qp_sweep_matches_reference_rd_points(tmp_path, golden_dir, mode):
     os.makedirs(out, exist_ok=True)
     json.dump(dict(points={str(k): v for k, v in logs.items()}, containers_byte_identical=exact),
               open(os.path.join(out, f"sweep_{mode}.json"), "w"), indent=1)
+
+
+@pytest.mark.gpu
+def test_manifest_run_two_workers_on_one_gpu_equals_one_worker(tmp_path, golden_dir):
+    """BASELINE.json configs[4] on the hardware at hand: the reference's job fan-out (test_video.py:417-532) through
+    harness.run_config - a manifest of two sequences x two rate points on a pool of 2 spawned workers sharing GPU 0
+    (-w may exceed the GPU count) writes the same .bin files, byte for byte, and the same rate / PSNR numbers as the
+    one-worker run, in the reference's log layout."""
+    import hashlib
+    import sys
+    sys.path.insert(0, golden_dir)
+    from make_golden_sweep import write_yuv420
+    W, H, N = 136, 200, 4
+    root = tmp_path / "data"
+    (root / "set").mkdir(parents=True)
+    for name, seed in (("a_136x200.yuv", 5), ("b_136x200.yuv", 6)):
+        write_yuv420(str(root / "set" / name), W, H, N, seed)
+    config = {"root_path": str(root), "test_classes": {"S": {"test": 1, "base_path": "set", "src_type": "yuv420", "sequences": {
+        "a_136x200.yuv": {"width": W, "height": H, "frames": N, "intra_period": -1},
+        "b_136x200.yuv": {"width": W, "height": H, "frames": N, "intra_period": 2}}}}}
+    logs, sums = {}, {}
+    for w in (1, 2):
+        sp = tmp_path / f"bins_w{w}"
+        logs[w] = harness.run_config(config, dict(qp_i=[10, 50], stream_path=str(sp), reset_interval=3, record_gpu=True),
+                                     workers=w, gpus=1)
+        sums[w] = {f: hashlib.sha256(open(os.path.join(sp, "S", f), "rb").read()).hexdigest() for f in sorted(os.listdir(sp / "S"))}
+    assert sorted(sums[1]) == ["a_136x200.yuv_q10.bin", "a_136x200.yuv_q50.bin", "b_136x200.yuv_q10.bin", "b_136x200.yuv_q50.bin"]
+    assert sums[1] == sums[2]
+    for seq in config["test_classes"]["S"]["sequences"]:
+        for key in ("000", "001"):
+            a, b = logs[1]["S"][seq][key], logs[2]["S"][seq][key]
+            assert a["gpu"] == b["gpu"] == 0 and a["qp_i"] == b["qp_i"] == (10, 50)[int(key)]
+            for k in ("ave_all_frame_bpp", "ave_all_frame_psnr", "i_frame_num", "p_frame_num"):
+                assert a[k] == b[k], (seq, key, k)
+    assert logs[1]["S"]["b_136x200.yuv"]["000"]["i_frame_num"] == 2
