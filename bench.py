@@ -22,9 +22,12 @@ broadcast once from rank 0 over RCCL).  Rank 0 prints ONE JSON line.
 Extra objects on the line:
   roofline     dominant kernel (dcb_tail128_kernel<256>: the DepthConvBlock tail, C = 256 at 136x240): algorithmic FLOP per
                launch / HIP-event time on its stream, against the 2.5 PFLOP/s dense f16 MFMA peak.
-  cpu_baseline the CPU oracle (port of the reference's torch fallback path) on the host cores: P frames of a
-               1/16-area crop (480x272), 2 warm-up + 3 timed frames, at 1 thread (what the reference harness
-               pins, src/utils/common.py:23) and at all cores, scaled to 1080p by the pixel ratio.
+  cpu_baseline the CPU oracle (port of the reference's torch fallback path) on the host cores: all cores on real
+               1080p P frames (1 warm-up + 2 timed, ~15 s); one thread (what the reference harness pins,
+               src/utils/common.py:23) on a 1/16-area crop, scaled and labelled so.
+  exact_mode   the fp32 mode that is bit-exact with the CPU oracle: P-frame encode / decode fps and the fraction of the
+               157.3 TFLOP/s fp32 MFMA peak.
+  gop_weighted_value   32 / (t_I + 31 t_P) from the timed window: does not depend on --steps.
 """
 import argparse
 import ctypes
@@ -168,9 +171,10 @@ def usable_cores():
 
 
 def cpu_baseline_leg():
-    """The oracle (CPU port of the reference path, fp32) on P frames of a 480x272 crop: warm-up (2 frames; 1 in the
-    single-thread leg) + 3 timed frames (encode + decode each) at 1 thread and at all cores, frames/s
-    scaled to the 1080p pixel count."""
+    """The oracle (CPU port of the reference path, fp32 C/OpenMP) on the host cores.  All-cores leg: REAL
+    1080p P frames (padded 1088x1920), 1 warm-up + 2 timed frames, encode + decode each (~5 s per frame on 16 cores) -
+    this is `value`.  One-thread leg (what the reference harness pins, src/utils/common.py:23): a 480x272 crop (1/16 of
+    the area), 1 warm-up + 3 timed frames, scaled by the pixel ratio and labelled so."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import dcvc_oracle as O
     O.lib()
@@ -179,35 +183,76 @@ def cpu_baseline_leg():
     except OSError:
         gomp = None
     ncores = usable_cores()
-    h, w = 272, 480
-    scale = (h * w) / float((HEIGHT + (-HEIGHT) % 16) * (WIDTH + (-WIDTH) % 16))
-    frames = [weights.synthetic_frame_yuv444(h, w, fi, 0) for fi in range(6)]
-    sps = dict(height=h, width=w, ec_part=0, use_ada_i=0)
-    out = {}
-    for label, nt in (("one_thread", 1), ("all_cores", ncores)):
+    H, W = HEIGHT + (-HEIGHT) % 16, WIDTH + (-WIDTH) % 16
+
+    def leg(h, w, nt, warm, timed):
         if gomp is not None:
             gomp.omp_set_num_threads(nt)
+        frames = [weights.synthetic_frame_yuv444(h, w, fi, 0) for fi in range(warm + timed + 1)]
+        sps = dict(height=h, width=w, ec_part=int(use_two_entropy_coders(h, w)), use_ada_i=0)
         enc_net = O.OracleDMC(weights.make_state_dict("dmc", 1234))
         dec_net = O.OracleDMC(weights.make_state_dict("dmc", 1234))
         for m in (enc_net, dec_net):
             m.update(THRES)
-            m.set_use_two_entropy_coders(False)
+            m.set_use_two_entropy_coders(bool(sps["ec_part"]))
             m.clear_dpb()
             m.add_ref_frame(None, frames[0])
         times = []
-        warm = 1 if nt == 1 and ncores > 1 else 2          # (the single-thread leg is ~5 s per frame: one warm-up there)
-        for fi in range(1, warm + 4):
+        for fi in range(1, warm + timed + 1):
             t0 = time.perf_counter()
             e = enc_net.compress(frames[fi], QP)
             dec_net.decompress(e["bit_stream"], sps, QP)
             times.append(time.perf_counter() - t0)
-        out[label] = scale * 3.0 / sum(times[warm:])
-        if nt == ncores:
-            break
-    return {"value": round(out.get("all_cores", out["one_thread"]), 4), "unit": "frames/s", "cores": ncores, "kind": "port",
-            "one_thread_value": round(out["one_thread"], 5), "cpu_model": cpu_model(),
-            "sample": "P frames of a 480x272 crop of the same synthetic sequence (1/16 of the padded 1080p area), warm-up + 3 "
-                      "timed frames per leg, encode + decode, fp32 C/OpenMP oracle; frames/s scaled by the pixel ratio"}
+        return timed / sum(times[warm:])
+
+    scale = (272 * 480) / float(H * W)
+    one = scale * leg(272, 480, 1, 1, 3)
+    full = leg(H, W, ncores, 1, 2) if ncores > 1 else one
+    return {"value": round(full, 4), "unit": "frames/s", "cores": ncores, "kind": "port",
+            "one_thread_value_scaled": round(one, 5), "cpu_model": cpu_model(),
+            "sample": "all cores: 1 warm-up + 2 timed P frames of the SAME workload (%dx%d padded to %dx%d), encode + decode, "
+                      "fp32 C/OpenMP oracle (port of the reference's torch fallback path); one_thread_value_scaled: 1 + 3 "
+                      "P frames of a 480x272 crop (1/16 of the area) on one thread, frames/s scaled by the pixel ratio - an "
+                      "extrapolation, not a measurement of the stated workload" % (WIDTH, HEIGHT, W, H)}
+
+
+def exact_mode_leg(device, world, rank, frames16):
+    """The fp32 'exact' mode (bit-exact with the CPU oracle: the repo's cross-device bit-exact mode)
+    on the same frames: 1 I + 6 P frames, encoder loop then decoder loop, every frame synchronised; fps over the P frames
+    and the fraction of the 157.3 TFLOP/s fp32 MFMA peak their conv work stands for."""
+    (ie, pe), (idec, pdec) = load_models(torch.float32, device, world, rank)
+    two = use_two_entropy_coders(HEIGHT, WIDTH)
+    for m in (ie, pe, idec, pdec):
+        m.set_use_two_entropy_coders(two)
+    n = 7
+    frames = [f.float() for f in frames16[:n]]
+    enc = SequenceEncoder(ie, pe, QP, intra_period=GOP, reset_interval=GOP)
+    dec = SequenceDecoder(idec, pdec, HEIGHT, WIDTH, two)
+    pkts, t_enc, t_dec = [], [], []
+    for rep in range(2):                      # the first pass captures the graphs
+        enc = SequenceEncoder(ie, pe, QP, intra_period=GOP, reset_interval=GOP)
+        dec = SequenceDecoder(idec, pdec, HEIGHT, WIDTH, two)
+        pkts, t_enc, t_dec = [], [], []
+        for k in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pkts += enc.encode(frames[k])
+            torch.cuda.synchronize()
+            t_enc.append(time.perf_counter() - t0)
+        for pkt in pkts:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dec.decode(pkt)
+            torch.cuda.synchronize()
+            t_dec.append(time.perf_counter() - t0)
+    scale = ((WIDTH + (-WIDTH) % 16) * (HEIGHT + (-HEIGHT) % 16)) / (1920.0 * 1088.0)
+    te, td = sum(t_enc[2:]) / (n - 2), sum(t_dec[2:]) / (n - 2)       # steady P frames (the one after the I frame differs)
+    return {"enc_fps": round(1.0 / te, 2), "dec_fps": round(1.0 / td, 2),
+            "enc_frac_of_157_TFLOPs": round(590.4e9 * scale / te / 157.3e12, 4),
+            "dec_frac_of_157_TFLOPs": round(691.6e9 * scale / td / 157.3e12, 4),
+            "i_frame_enc_ms": round(1e3 * t_enc[0], 2), "i_frame_dec_ms": round(1e3 * t_dec[0], 2),
+            "note": "fp32 storage, v_mfma_f32_16x16x4_f32, explicit fma order: tensors, symbols and streams bit-exact with the "
+                    "CPU oracle (tests/test_gpu_codec.py); 5 steady P frames, sequential, each frame synchronised"}
 
 
 def main():
@@ -216,6 +261,7 @@ def main():
     ap.add_argument("--steps", type=int, default=256)     # eight whole GOPs (I frames at the GOP's rate, 1 in 32), under a second
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-mode", action="store_true", help="skip the fp32 exact-mode leg")
     ap.add_argument("--frame", default="1920x1080",
                     help="WxH of the synthetic sequence (default: the BASELINE.json configs[1] size; 3840x2160 = configs[3])")
     ap.add_argument("--roofline-only", action="store_true",
@@ -253,7 +299,7 @@ def main():
     # of frame n+1 (opendcvc_amd/pipeline.py); every timed frame is still completed inside the timed region (flush)
     dec = SequenceDecoder(idec, pdec, HEIGHT, WIDTH, two, defer_output=True)
 
-    state = {"i": 0, "t_enc": 0.0, "t_dec": 0.0, "bytes": 0, "n_i": 0, "j": 0, "seq_bytes": 0, "psnr": []}
+    state = {"i": 0, "t_enc": 0.0, "t_dec": 0.0, "bytes": 0, "n_i": 0, "j": 0, "seq_bytes": 0, "psnr": [], "done": [], "kinds": []}
     pipe = EncodeDecodePipeline(enc, dec, device)
     s_enc, s_dec = pipe.enc_stream, pipe.dec_stream
 
@@ -268,9 +314,12 @@ def main():
             if timed:
                 state["bytes"] += len(pkt.bit_stream)
                 state["n_i"] += int(pkt.is_i)
+                state["kinds"].append(bool(pkt.is_i))
 
         def on_frame(_):
             state["j"] += 1
+            if timed:
+                state["done"].append(time.perf_counter())      # (host time of the frame's hand-over by the decoder stage)
 
         pipe.run((frames[k % GOP] for k in range(first, first + nsteps)), on_packet, on_frame)
 
@@ -324,6 +373,14 @@ def main():
         state["psnr"].append(yuv420_distortion(x_hat, *planes[k]))
     psnr = np.mean(np.asarray(state["psnr"], np.float64), axis=0)
 
+    # A figure that does not depend on where a short window sits in the GOP: the time of a P frame = the median interval
+    # between two completed frames of the timed window, the time of an I frame = what is left of the window per I frame;
+    # one GOP = 1 I + 31 P.  (With whole GOPs in the window - the default - this is `value`.)
+    gaps = np.diff(np.asarray(state["done"], np.float64)) if len(state["done"]) > 2 else np.asarray([elapsed / K])
+    t_p = float(np.median(gaps))
+    t_i = max(t_p, (elapsed - (K - state["n_i"]) * t_p) / max(1, state["n_i"]))
+    gop_weighted = GOP / (t_i + (GOP - 1) * t_p)
+
     if rank == 0:
         N = world
         value = N * K / elapsed
@@ -338,11 +395,16 @@ def main():
             "value": round(value, 3), "unit": "frames/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": round(seq_value / base, 4), "dtype": "f16", "data": "synthetic",
+            "gop_weighted_value": round(N * gop_weighted, 3),
+            "gop_weighted_note": "frames/s of one 32-frame GOP = 32 / (t_I + 31 t_P), t_P = median interval between completed "
+                                 "frames of the timed window (%.3f ms), t_I = the rest of the window per I frame (%.3f ms): "
+                                 "independent of --steps" % (1e3 * t_p, 1e3 * t_i),
             "config": {"workload": "DCVC-RT inter-coding, %s YUV420 32-frame GOP, single q (qp 32), one stream per MI355X "
                                    "(BASELINE.json configs[%d])" % (("1080p", 1) if (WIDTH, HEIGHT) == (1920, 1080) else (args.frame, 3)),
                        "frame": "%dx%d padded to %dx%d" % (WIDTH, HEIGHT, WIDTH + (-WIDTH) % 16, HEIGHT + (-HEIGHT) % 16), "intra_period": GOP, "i_frames_timed": state["n_i"],
                        "i_frame_share_timed": round(state["n_i"] / float(K), 4), "i_frame_share_gop": round(1.0 / GOP, 4),
                        "alignment_frames": align, "cpus_per_rank": len(cpus) if cpus else len(os.sched_getaffinity(0)),
+                       "cpus_granted": dist_utils.cpus_granted(int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))),
                        "entropy_coders": 2 if two else 1, "force_zero_thres": THRES,
                        "weights": "synthetic seed 1234 (opendcvc_amd/weights.py)",
                        "pipeline": "encoder and decoder on two host threads / two HIP streams of the same GPU: frame n "
@@ -374,6 +436,8 @@ def main():
             "enc_frac_hbm": round(0.76e9 * scale / t_enc / 8.0e12, 4), "dec_frac_hbm": round(0.78e9 * scale / t_dec / 8.0e12, 4),
             "note": "P-frame work only; the timed pass includes the GOP's I frame and the host entropy coding"}
         out["roofline"] = roofline_leg(pe, device, dtype)
+        if world == 1 and not args.no_exact_mode:
+            out["exact_mode"] = exact_mode_leg(device, world, rank, frames)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg()
         print(json.dumps(out), flush=True)
