@@ -236,7 +236,7 @@ def exact_mode_leg(device, world, rank, frames16):
         for k in range(n):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            pkts += enc.encode(frames[k])
+            pkts.append(enc.encode(frames[k]))
             torch.cuda.synchronize()
             t_enc.append(time.perf_counter() - t0)
         for pkt in pkts:
