@@ -218,7 +218,10 @@ class CompressionModel(tnn.Module):
         sd = self.state_dict()
         pre = "bit_estimator_z."
         params = {k[len(pre):]: v.detach().float().cpu() for k, v in sd.items() if k.startswith(pre)}
-        params.update(self._z_master or {})       # fp32 values saved by half(): same tables before and after half()
+        if self._z_master is None and any(v.dtype != torch.float32 for k, v in sd.items() if k.startswith(pre)):
+            raise DcvcError("update(): only fp16 copies of bit_estimator_z are left (the model was converted without "
+                            "half() / load_state_dict of fp32 tensors): the z CDF tables would differ from the reference's")
+        params.update(self._z_master or {})       # fp32 master values: same tables before and after the conversion
         self._z_group = self.entropy_coder.add_cdf(*entropy.factorized_cdf_tables(params, self.qp_total, self.z_channel))
 
     def half(self):
@@ -231,9 +234,15 @@ class CompressionModel(tnn.Module):
                               if k.startswith(pre)}
         return super().half()
 
-    def load_state_dict(self, *args, **kwargs):
-        self._z_master = None
-        return super().load_state_dict(*args, **kwargs)
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """The incoming checkpoint's fp32 bit_estimator_z.* tensors are kept as the master copy for the CDF tables, so a
+        model that is already half() - or gets converted by .to(torch.float16) / _apply instead of .half() - still
+        builds the reference's tables (the reference builds them in fp32 before .half(), test_video.py:398-404)."""
+        pre = "bit_estimator_z."
+        master = {k[len(pre):]: v.detach().float().cpu().clone() for k, v in state_dict.items()
+                  if k.startswith(pre) and torch.is_tensor(v) and v.dtype == torch.float32}
+        self._z_master = master or None
+        return super().load_state_dict(state_dict, *args, **kwargs)
 
     def set_use_two_entropy_coders(self, use_two_entropy_coders):
         self.entropy_coder.set_use_two_entropy_coders(use_two_entropy_coders)
@@ -587,6 +596,13 @@ class DMC(CompressionModel):
             pd["x_hat"] = self._picture_out(head)
 
     def finish_output(self):
+        """finish_output under CAPTURE_GUARD.frame(): called directly from two host threads (the reference-compatible API, not only
+        through SequenceEncoder / SequenceDecoder), a frame never synchronises or allocates while another thread's
+        GraphCache.run is capturing.  The scope is re-entrant per thread."""
+        with CAPTURE_GUARD.frame():
+            return self._finish_output_unguarded()
+
+    def _finish_output_unguarded(self):
         """Deferred decoder output: completes and returns the reconstruction of the last decompress(...,
         defer_output=True) (None if there is none).  Called implicitly by the next decompress."""
         if self._pending is None:
@@ -630,12 +646,26 @@ class DMC(CompressionModel):
         return ec.get_encoded_stream()
 
     def finish_stream(self):
+        """finish_stream under CAPTURE_GUARD.frame(): called directly from two host threads (the reference-compatible API, not only
+        through SequenceEncoder / SequenceDecoder), a frame never synchronises or allocates while another thread's
+        GraphCache.run is capturing.  The scope is re-entrant per thread."""
+        with CAPTURE_GUARD.frame():
+            return self._finish_stream_unguarded()
+
+    def _finish_stream_unguarded(self):
         """Deferred encoder stream: entropy-codes and returns the bit stream of the last compress(..., defer_stream=True)
         (None if there is none).  Called implicitly by the next compress."""
         job, self._stream_pending = self._stream_pending, None
         return None if job is None else self._code_symbols(job)
 
     def compress(self, x, qp, defer_stream=False):
+        """compress under CAPTURE_GUARD.frame(): called directly from two host threads (the reference-compatible API, not only
+        through SequenceEncoder / SequenceDecoder), a frame never synchronises or allocates while another thread's
+        GraphCache.run is capturing.  The scope is re-entrant per thread."""
+        with CAPTURE_GUARD.frame():
+            return self._compress_unguarded(x, qp, defer_stream=defer_stream)
+
+    def _compress_unguarded(self, x, qp, defer_stream=False):
         """video_model.py:299-341.  x: [1,3,H,W] in [0,1], H and W multiples of 16.
         Two captured runs: everything up to the symbol hand-off, then the decoder (which overlaps the host
         entropy coding).
@@ -712,6 +742,13 @@ class DMC(CompressionModel):
         return {"bit_stream": bit_stream} if prev is None else {"bit_stream": bit_stream, "bit_stream_prev": prev}
 
     def decompress(self, bit_stream, sps, qp, defer_output=False):
+        """decompress under CAPTURE_GUARD.frame(): called directly from two host threads (the reference-compatible API, not only
+        through SequenceEncoder / SequenceDecoder), a frame never synchronises or allocates while another thread's
+        GraphCache.run is capturing.  The scope is re-entrant per thread."""
+        with CAPTURE_GUARD.frame():
+            return self._decompress_unguarded(bit_stream, sps, qp, defer_output=defer_output)
+
+    def _decompress_unguarded(self, bit_stream, sps, qp, defer_output=False):
         """video_model.py:343-376.  Five captured runs, separated by the three host decoding steps
         (z, first and second checkerboard half).
 
@@ -846,6 +883,13 @@ class DMCI(CompressionModel):
         return L.dcb_chain([n["sp_adaptor"][step]] + n["spatial"], y_hat, common, then_conv=n["spatial_out"])
 
     def compress(self, x, qp):
+        """compress under CAPTURE_GUARD.frame(): called directly from two host threads (the reference-compatible API, not only
+        through SequenceEncoder / SequenceDecoder), a frame never synchronises or allocates while another thread's
+        GraphCache.run is capturing.  The scope is re-entrant per thread."""
+        with CAPTURE_GUARD.frame():
+            return self._compress_unguarded(x, qp)
+
+    def _compress_unguarded(self, x, qp):
         """image_model.py:143-185 + compress_prior_4x (common_model.py:206-256).  Two captured runs, like DMC:
         everything up to the symbol hand-off, then the synthesis transform (which overlaps the host entropy coder)."""
         dtype, device = self._ensure_layers()
@@ -894,6 +938,13 @@ class DMCI(CompressionModel):
         return {"bit_stream": bit_stream, "x_hat": x_hat}
 
     def decompress(self, bit_stream, sps, qp):
+        """decompress under CAPTURE_GUARD.frame(): called directly from two host threads (the reference-compatible API, not only
+        through SequenceEncoder / SequenceDecoder), a frame never synchronises or allocates while another thread's
+        GraphCache.run is capturing.  The scope is re-entrant per thread."""
+        with CAPTURE_GUARD.frame():
+            return self._decompress_unguarded(bit_stream, sps, qp)
+
+    def _decompress_unguarded(self, bit_stream, sps, qp):
         """image_model.py:187-209 + decompress_prior_4x (common_model.py:258-296).  Five captured runs split at the
         four host decoding steps (the reference's dependency structure: each checkerboard step needs the symbols of
         the previous one); a run never updates an earlier run's output in place (GraphCache), so every step restores

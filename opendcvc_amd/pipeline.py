@@ -158,12 +158,23 @@ class EncodeDecodePipeline:
             try:
                 torch.cuda.set_device(self.device)
                 with torch.cuda.stream(self.enc_stream):
-                    for x in frames:
-                        with CAPTURE_GUARD.frame():         # the callback may touch the device too
-                            pkt = self.encoder.encode(x)
+                    def emit(pkts):
+                        # a deferring encoder (SequenceEncoder(defer_stream=True)) returns a LIST of packets - the previous
+                        # frame's, possibly none - and keeps the last one until flush()
+                        for pkt in (pkts if isinstance(pkts, (list, tuple)) else [pkts]):
                             if on_packet is not None:
-                                on_packet(pkt)
-                        q.put(pkt)                          # (never block on the queue inside the scope)
+                                with CAPTURE_GUARD.frame():     # the callback may touch the device too
+                                    on_packet(pkt)
+                            q.put(pkt)                          # (never block on the queue inside the scope)
+
+                    for x in frames:
+                        with CAPTURE_GUARD.frame():
+                            pkts = self.encoder.encode(x)
+                        emit(pkts)
+                    if getattr(self.encoder, "defer", False):
+                        with CAPTURE_GUARD.frame():
+                            pkts = self.encoder.flush()
+                        emit(pkts)
                     with CAPTURE_GUARD.frame():
                         self.enc_stream.synchronize()
             except BaseException as e:                      # re-raised by run()

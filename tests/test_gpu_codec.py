@@ -71,6 +71,7 @@ def test_fp32_bit_exact_with_oracle_and_within_tolerance_of_reference(seqs, name
 def test_fp16_self_consistent_and_close_to_fp32(seqs):
     rec = seqs["seq_256"]
     got = run_hip(rec, torch.float16)
+    devs = []
     for fi, g in enumerate(got):
         if fi > 0:   # decoder reproduces the encoder's reference feature bit for bit
             assert np.array_equal(g["dec_feature"], g["feature"]), f"frame {fi}: fp16 enc/dec desync"
@@ -79,9 +80,18 @@ def test_fp16_self_consistent_and_close_to_fp32(seqs):
         # 4 % (the two runs quantise slightly different latents from the second frame on, and a ~2 KB frame of this
         # random-weight model moves by 1-2.5 % with the compiler's instruction selection alone), the sequence's within 2 %
         # - the bounds of test_qp_sweep_matches_reference_rd_points
-        assert abs(len(g["bits"]) - f["bytes"]) <= 0.04 * f["bytes"], (fi, len(g["bits"]), f["bytes"])
+        # 2 % on frames of 4 KB and more, 4 % below (there one flipped symbol is already ~0.1 %); the measured per-frame
+        # deviations are written to gpurun_out/f16_frame_rate_dev.json so that the bound stays justified by data
+        dev = (len(g["bits"]) - f["bytes"]) / f["bytes"]
+        devs.append(dict(frame=fi, bytes_ref=f["bytes"], bytes=len(g["bits"]), rel=round(dev, 5)))
+        assert abs(dev) <= (0.02 if f["bytes"] >= 4096 else 0.04), (fi, len(g["bits"]), f["bytes"])
         assert abs(psnr_of(rec, fi, g["x_hat"]) - f["psnr"]) < 0.05
     total, want = sum(len(g["bits"]) for g in got), sum(f["bytes"] for f in rec["frames"])
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(dict(frames=devs, total_rel=round((total - want) / want, 5)), open(os.path.join(out, "f16_frame_rate_dev.json"), "w"))
     assert abs(total - want) <= 0.02 * want, (total, want)
 
 
@@ -330,3 +340,27 @@ def test_deferred_encoder_stream_equals_immediate(dtype):
     for fi, (a, b) in enumerate(zip(*outs)):
         assert (a.is_i, a.qp, a.use_ada_i) == (b.is_i, b.qp, b.use_ada_i), fi
         assert a.bit_stream == b.bit_stream, f"frame {fi}: deferred stream differs"
+
+
+def test_pipeline_with_deferring_encoder_emits_every_packet(seqs):
+    """EncodeDecodePipeline with SequenceEncoder(defer_stream=True): encode() then returns lists (the previous frame's
+    packet, possibly none) and the last packet only comes out of flush() - the pipeline forwards every packet, in order,
+    and the decoded pictures equal the plain sequential run's."""
+    from opendcvc_amd.pipeline import EncodeDecodePipeline, SequenceDecoder, SequenceEncoder
+    rec = seqs["seq_64_two"] if "seq_64_two" in seqs else seqs["seq_256"]
+    h, w, qp = rec["h"], rec["w"], rec["qp"]
+    n = min(5, len(rec["frames"]))
+    frames = [torch.from_numpy(weights.synthetic_frame_yuv444(h, w, fi, 0)).cuda().half() for fi in range(n)]
+    outs = {}
+    for defer in (False, True):
+        (ie, pe), (idec, pdec) = hip_codecs(rec["seed"], rec["thres"], torch.float16), hip_codecs(rec["seed"], rec["thres"], torch.float16)
+        for m in (ie, pe, idec, pdec):
+            m.set_use_two_entropy_coders(bool(rec["two"]))
+        enc = SequenceEncoder(ie, pe, qp, intra_period=-1, reset_interval=0, defer_stream=defer)
+        dec = SequenceDecoder(idec, pdec, h, w, bool(rec["two"]), defer_output=True)
+        pkts, pics = [], []
+        EncodeDecodePipeline(enc, dec, torch.device("cuda", 0)).run(frames, lambda p: pkts.append(p.bit_stream),
+                                                                   lambda x: pics.append(x.float().cpu().numpy()))
+        outs[defer] = (pkts, pics)
+    assert len(outs[True][0]) == len(outs[False][0]) == n and outs[True][0] == outs[False][0]
+    assert len(outs[True][1]) == n and all(np.array_equal(a, b) for a, b in zip(outs[True][1], outs[False][1]))
