@@ -46,21 +46,23 @@ constexpr int LDS_S = DW_SLAB;                // halo slab rows unpadded: 8 lane
 
 template <int C>
 struct Cfg {
-    static_assert(C % 128 == 0, "four channel quarters x whole 32-channel tiles");
-    static constexpr int NT = C / 32;                 // output channel tiles
-    static constexpr int NTW = NT / 4;                // ... per channel quarter
+    static_assert(C % 64 == 0, "DepthConvBlock widths are padded to 64");
+    static constexpr int NT = C / 32;                 // output channel tiles; tile cq + 4 i belongs to channel quarter cq
+    static constexpr int NTW = (NT + 3) / 4;          // ... per channel quarter (C = 320: 3, 3, 2, 2 - the two missing
+    static constexpr bool RAG = NT % 4 != 0;          // tiles run on zero weights and are dropped)
     static constexpr int KS = C / 16;                 // k-steps over C
     static constexpr int NCH = 2 * C / VC;            // FFN chunks
     static constexpr int F4 = 4 * NTW;                // fragments of one W4 chunk pass
     // ring depth: fragments requested ahead of their use.  Every phase's ring slots are static: phases start at a
     // compile-time offset into the ring
-    static constexpr int D = F4;
+    static constexpr int D = 8;
     static constexpr int LDX = C + PAD;
     static constexpr int FRAGS = KS * NTW + NCH * KS + NCH * F4;   // fragments per channel quarter
     static constexpr int STREAM = FRAGS + D;          // + D dummies: the ring refill never needs a clamp
     static constexpr size_t v_elems = (size_t)2 * M * LDV > (size_t)2 * HALO * LDS_S ? (size_t)2 * M * LDV : (size_t)2 * HALO * LDS_S;
     static constexpr size_t LDS = ((size_t)M * LDX + v_elems) * sizeof(half_t);
     static_assert(NCH % 2 == 0 && NCH >= 4, "the chunk loop is unrolled by two");
+    static_assert((2 * C) % VC == 0, "whole FFN chunks");
     // ring offsets (fragments consumed so far, mod D) at the start of: u(0), step 0, the odd / even steps of the loop,
     // the last step, the final W4 pass
     static constexpr int OFF_U0 = (KS * NTW) % D;
@@ -152,18 +154,13 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
 #pragma unroll
     for (int sl = 1; sl < nslab; ++sl) fetch(sl);
     constexpr int NID = M * GC / NTHR;
-    static_assert((M * GC) % NTHR == 0, "identity pass");
-    // identity / output pass, item k of this thread -> (pixel m, channel group c); where the thread count is a multiple of
-    // the groups per pixel a thread keeps its channel group (no division per item)
+    // identity / output pass: item k of this thread -> pixel m = tid / 8 + 64 (k / G8), channel group tid % 8 + 8 (k % G8)
+    // (eight threads cover 128 contiguous bytes of a pixel; no division per item, nothing to keep in registers)
+    constexpr int G8 = C / 64;
+    static_assert(NID == 2 * G8 && NTHR / 8 == M / 2, "identity pass mapping");
     auto idmap = [&](int k, int& m, int& c) __attribute__((always_inline)) {
-        if constexpr (NTHR % GC == 0) {
-            c = (tid % GC) * V;
-            m = tid / GC + k * (NTHR / GC);
-        } else {
-            const int it = tid + k * NTHR;
-            m = it / GC;
-            c = (it - m * GC) * V;
-        }
+        c = ((tid & 7) + 8 * (k % G8)) * V;
+        m = (tid >> 3) + (M / 2) * (k / G8);
     };
     Vec16 idv[NID];
     auto ident_fetch = [&]() __attribute__((always_inline)) {
@@ -240,13 +237,24 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
         return *reinterpret_cast<const half8*>(xb + t * 32 * LDX + s * 16);
     };
 
+    // output channel tile i of this wave = tile cqw + 4 i of the block (exists unless the width is ragged)
+    auto tile_of = [&](int i) __attribute__((always_inline)) { return cqw + 4 * i; };
+    auto tile_exists = [&](int i) __attribute__((always_inline)) { return !CF::RAG || cqw + 4 * i < CF::NT; };
     // epilogue biases of this lane's rows (quads 8 g + 4 hh of each channel tile): requested ahead of the GEMM they follow
-    floatx4 ebias[NTW][4];
+    // where the registers allow (two tiles per wave)
+    constexpr bool EB_PRE = NTW <= 2;
+    floatx4 ebias[EB_PRE ? NTW : 1][4];
     auto ebias_load = [&](const float* b) __attribute__((always_inline)) {
+        if constexpr (EB_PRE) {
 #pragma unroll
-        for (int i = 0; i < NTW; ++i)
+            for (int i = 0; i < NTW; ++i)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) ebias[i][g] = load_f4(b + 32 * (cqw * NTW + i) + 4 * hh + 8 * g);
+                for (int g = 0; g < 4; ++g) ebias[i][g] = load_f4(b + 32 * tile_of(i) + 4 * hh + 8 * g);
+        }
+    };
+    auto ebias_get = [&](const float* b, int i, int g) __attribute__((always_inline)) {
+        if constexpr (EB_PRE) return ebias[i][g];
+        return load_f4(b + 32 * tile_of(i) + 4 * hh + 8 * g);
     };
     ebias_load(p.b2);
 
@@ -279,10 +287,11 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
     // (W2 d + b2) -> fp16 -> bufX
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        const int chb = 32 * (cqw * NTW + i) + 4 * hh;
+        if (!tile_exists(i)) continue;
+        const int chb = 32 * tile_of(i) + 4 * hh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const floatx4 bias = ebias[i][g];
+            const floatx4 bias = ebias_get(p.b2, i, g);
 #pragma unroll
             for (int t = 0; t < PTW; ++t) {
                 floatx4 v = {acc[i][t][4 * g], acc[i][t][4 * g + 1], acc[i][t][4 * g + 2], acc[i][t][4 * g + 3]};
@@ -430,10 +439,11 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
     // ---- r = (W4 v + b4) + o, in place in bufX (each element is owned by one lane)
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        const int chb = 32 * (cqw * NTW + i) + 4 * hh;
+        if (!tile_exists(i)) continue;
+        const int chb = 32 * tile_of(i) + 4 * hh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const floatx4 bias = ebias[i][g];
+            const floatx4 bias = ebias_get(p.b4, i, g);
 #pragma unroll
             for (int t = 0; t < PTW; ++t) {
                 const floatx4 o = lds_load_quad<half_t>(bufX, LDX, prow + 32 * t, chb + 8 * g);
@@ -491,18 +501,23 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
     if (p.nw1 != nullptr) {
         // Fused head of the next block / fused 1x1 conv on the tile still in bufX: the 16x16x32 GEMM of gemm_core.hpp in
         // the k order of dcb_head_kernel / conv_kernel, so the values are bit-identical to the separate launch.
-        constexpr int MT8 = M / 16, NT16 = C / (16 * NW);   // 16-channel tiles per wave (all 128 pixels)
-        using frag_t = typename TR::frag_t;
-        int tiles[NT16];
+        constexpr int MT8 = M / 16, NT16 = (C / 16 + NW - 1) / NW;   // 16-channel tiles per wave (all 128 pixels)
+        constexpr bool RAG16 = (C / 16) % NW != 0;                    // (C = 320: 20 tiles on 8 waves - the waves without a
+        using frag_t = typename TR::frag_t;                           //  third tile run it on a clamped weight tile and drop it)
+        int tiles[NT16], wtiles[NT16];
 #pragma unroll
-        for (int i = 0; i < NT16; ++i) tiles[i] = wave + NW * i;
+        for (int i = 0; i < NT16; ++i) {
+            tiles[i] = wave + NW * i;
+            wtiles[i] = RAG16 ? min(tiles[i], C / 16 - 1) : tiles[i];
+        }
         const int pl16 = lane & 15, cq = (lane >> 4) * 4;
         floatx4 acc1[MT8][NT16];
         zero_acc(acc1);
-        gemm_acc<half_t, MT8, NT16, 2>(acc1, bufX, LDX, C / KG, reinterpret_cast<const frag_t*>(p.nw1), C / KG, 0, tiles, lane);
+        gemm_acc<half_t, MT8, NT16, 2>(acc1, bufX, LDX, C / KG, reinterpret_cast<const frag_t*>(p.nw1), C / KG, 0, wtiles, lane);
         __syncthreads();   // every wave has finished reading r
 #pragma unroll
         for (int i = 0; i < NT16; ++i) {
+            if (RAG16 && tiles[i] >= C / 16) continue;
             const int ch0 = tiles[i] * 16 + cq;
             const floatx4 bias = load_f4(p.nb1 + ch0);
             floatx4 qv = {1.f, 1.f, 1.f, 1.f};

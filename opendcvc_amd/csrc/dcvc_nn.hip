@@ -939,7 +939,7 @@ int upload_T(DevBuf& dst, int n, const std::function<float(int)>& get)
 struct dcvc_dcb {
     int dtype, cin, c, cin_p, c_p, shortcut, adapt;
     DevBuf wa, ba, w1, b1, wd, bd, w2, b2, w3, b3, w4, b4;
-    DevBuf wt128;   // fp16, widths 256 / 384: W2 | W3 | W4 once more as the fragment streams of dcb_tail128_kernel
+    DevBuf wt128;   // fp16, widths 256 / 320 / 384: W2 | W3 | W4 once more as the fragment streams of dcb_tail128_kernel
 };
 
 struct dcvc_conv {
@@ -1015,10 +1015,10 @@ int pack_t128(DevBuf& dst, const std::function<float(int, int)>& W2, const std::
         };
         auto g4 = [&](int j) {
             for (int s4 = 0; s4 < 4; ++s4)
-                for (int i = 0; i < CF::NTW; ++i) put(W4, [&](int r) { return 32 * (wave * CF::NTW + i) + r; }, 4 * j + s4);
+                for (int i = 0; i < CF::NTW; ++i) put(W4, [&](int r) { return 32 * (wave + 4 * i) + r; }, 4 * j + s4);
         };
         for (int s = 0; s < CF::KS; ++s)
-            for (int i = 0; i < CF::NTW; ++i) put(W2, [&](int r) { return 32 * (wave * CF::NTW + i) + r; }, s);
+            for (int i = 0; i < CF::NTW; ++i) put(W2, [&](int r) { return 32 * (wave + 4 * i) + r; }, s);
         g3(0);
         for (int j = 0; j < CF::NCH; ++j) {
             if (j >= 1) g4(j - 1);
@@ -1033,7 +1033,7 @@ int pack_t128(DevBuf& dst, const std::function<float(int, int)>& W2, const std::
     return dst.upload(buf.data(), buf.size() * sizeof(half_t));
 }
 
-inline bool t128_width_ok(int c_p) { return c_p == 256 || c_p == 384; }
+inline bool t128_width_ok(int c_p) { return c_p == 256 || c_p == 320 || c_p == 384; }
 
 // DCVC_T128=0 keeps the 64-pixel tails on large maps (A/B measurements; both forms pass the same layer tests)
 static bool t128_enabled()
@@ -1208,7 +1208,7 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         tp.stamps = d_stamps;
     }
 #endif
-    if constexpr (sizeof(T) == 2 && MT == 4 && (NTW == 4 || NTW == 6)) {
+    if constexpr (sizeof(T) == 2 && MT == 4 && (NTW == 4 || NTW == 5 || NTW == 6)) {
         // large maps, widths 256 / 384: 128-pixel tiles, one 4-wave workgroup per CU, gate pipelined into the MFMA stream
         if (h->wt128.p != nullptr && t128_enabled() && !head_in) {
             tp.wt = h->wt128.p;
@@ -1428,7 +1428,8 @@ int dcvc_dcb_create(int dtype, int cin, int c, int shortcut, const float* adapto
         auto W2 = [&](int n, int k) { return (n < C && k < C) ? w2[(size_t)n * C + k] : 0.f; };
         auto W3 = [&](int n, int k) { const int rr = u_row(n); return (rr >= 0 && k < C) ? ka * w3[(size_t)rr * C + k] : 0.f; };
         auto W4 = [&](int n, int k) { return (n < C && k < 2 * C) ? w4[(size_t)n * 2 * C + k] / ka : 0.f; };
-        rc |= Cp == 256 ? pack_t128<256>(h->wt128, W2, W3, W4) : pack_t128<384>(h->wt128, W2, W3, W4);
+        rc |= Cp == 256 ? pack_t128<256>(h->wt128, W2, W3, W4)
+                        : Cp == 320 ? pack_t128<320>(h->wt128, W2, W3, W4) : pack_t128<384>(h->wt128, W2, W3, W4);
     }
     if (rc) return rc < 0 ? rc : dcvc::E_MEM;
     *out = h.release();
