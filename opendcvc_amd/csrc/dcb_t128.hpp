@@ -60,7 +60,12 @@ struct Cfg {
     static constexpr int FRAGS = KS * NTW + NCH * KS + NCH * F4;   // fragments per channel quarter
     static constexpr int STREAM = FRAGS + D;          // + D dummies: the ring refill never needs a clamp
     static constexpr size_t v_elems = (size_t)2 * M * LDV > (size_t)2 * HALO * LDS_S ? (size_t)2 * M * LDV : (size_t)2 * HALO * LDS_S;
-    static constexpr size_t LDS = ((size_t)M * LDX + v_elems) * sizeof(half_t);
+    // small tables staged in LDS once (every thread needs them, 8 - 64 threads each the same 16 bytes: through the L1 that
+    // is 90 KB of requests per slab for the depthwise taps alone): depthwise taps [9][C] halfs, depthwise bias [C] floats,
+    // FFN bias [4 C] floats
+    static constexpr size_t TAB_BYTES = (size_t)9 * C * 2 + (size_t)C * 4 + (size_t)4 * C * 4;
+    static constexpr size_t LDS = ((size_t)M * LDX + v_elems) * sizeof(half_t) + TAB_BYTES;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(NCH % 2 == 0 && NCH >= 4, "the chunk loop is unrolled by two");
     static_assert((2 * C) % VC == 0, "whole FFN chunks");
     // ring offsets (fragments consumed so far, mod D) at the start of: u(0), step 0, the odd / even steps of the loop,
@@ -91,6 +96,9 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
     extern __shared__ __attribute__((aligned(32))) char smem[];
     half_t* bufX = reinterpret_cast<half_t*>(smem);
     half_t* bufV = bufX + M * LDX;
+    half_t* tabW = bufV + CF::v_elems;                                   // [9][C] depthwise taps
+    float* tabBd = reinterpret_cast<float*>(tabW + 9 * C);               // [C]
+    float* tabB3 = tabBd + C;                                            // [4 C]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cqw = wave & 3, ph = wave >> 2;          // channel quarter, pixel half
@@ -122,35 +130,50 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
     constexpr int nslab = C / DW_SLAB;
     const half_t* wd = reinterpret_cast<const half_t*>(p.wd);
     const int dcs = (tid % GS) * V;                      // this thread's channel group inside a slab
-    // halo pixel of load k of this thread: element offset of its row in `a` (or -1 outside the picture), the same for
-    // every slab
-    int hoff[NLD];
+    // Buffer loads with a range-checked descriptor: a halo pixel outside the picture gets an offset beyond the buffer and
+    // reads zeros (the depthwise conv's padding).  No branch around a load - hipcc stops counting vmcnt behind one and
+    // waits for EVERYTHING in flight, which would serialise the loads requested up front.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int OOB = 0x7FFFFFF0;
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(a), 0, (int)((long)p.H * p.W * p.lda * 2), 0x00020000);
+    int hoff[NLD];       // byte offset of this thread's load k of a slab (the same for every slab)
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         const int hp = tid / GS + k * (NTHR / GS);
         const int y = ty0 - 1 + hp / HW_, x = tx0 - 1 + hp % HW_;
-        hoff[k] = (hp < HALO && y >= 0 && y < p.H && x >= 0 && x < p.W) ? (y * p.W + x) * (int)p.lda + dcs : -1;
+        hoff[k] = (hp < HALO && y >= 0 && y < p.H && x >= 0 && x < p.W) ? ((y * p.W + x) * (int)p.lda + dcs) * 2 : OOB;
+#ifdef DCVC_DIAG
+        if (p.ablate & 32) hoff[k] = (tid & 255) * 16;      // timing experiment: every load hits the same 4 KiB
+#endif
     }
     Vec16 pre[nslab][NLD];
     auto fetch = [&](int slab) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            Vec16 v = VEC16_ZERO;
-            if (hoff[k] >= 0) v = *reinterpret_cast<const Vec16*>(a + hoff[k] + slab * DW_SLAB);
-            pre[slab][k] = v;
-        }
+        for (int k = 0; k < NLD; ++k)
+            pre[slab][k] = __builtin_bit_cast(Vec16, __builtin_amdgcn_raw_buffer_load_b128(arsrc, hoff[k], slab * DW_SLAB * 2, 0));
     };
-    Vec16 wtap[9], wtap_n[9];
-    floatx4 bd0, bd1, bd0_n, bd1_n;
+    Vec16 wtap[9];
+    floatx4 bd0, bd1;
     auto taps_fetch = [&](int slab) __attribute__((always_inline)) {
         const int c = slab * DW_SLAB + dcs;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wtap_n[t] = *reinterpret_cast<const Vec16*>(wd + t * C + c);
-        bd0_n = load_f4(p.bd + c);
-        bd1_n = load_f4(p.bd + c + 4);
+        for (int t = 0; t < 9; ++t) wtap[t] = *reinterpret_cast<const Vec16*>(tabW + t * C + c);
+        bd0 = *reinterpret_cast<const floatx4*>(tabBd + c);
+        bd1 = *reinterpret_cast<const floatx4*>(tabBd + c + 4);
     };
     fetch(0);
-    taps_fetch(0);
+    // the small tables -> LDS (visible after the first barrier of the depthwise stage); requested behind slab 0, in
+    // front of the other slabs: their LDS stores wait for nothing else
+    {
+        constexpr int NW16 = 9 * C * 2 / 16, NB16 = C * 4 / 16, N316 = 4 * C * 4 / 16;
+        for (int i = tid; i < NW16 + NB16 + N316; i += NTHR) {
+            const Vec16* src = i < NW16 ? reinterpret_cast<const Vec16*>(wd) + i
+                               : i < NW16 + NB16 ? reinterpret_cast<const Vec16*>(p.bd) + (i - NW16)
+                                                 : reinterpret_cast<const Vec16*>(p.b3) + (i - NW16 - NB16);
+            reinterpret_cast<Vec16*>(tabW)[i] = *src;      // (the three tables are contiguous in LDS)
+        }
+    }
 #pragma unroll
     for (int sl = 1; sl < nslab; ++sl) fetch(sl);
     constexpr int NID = M * GC / NTHR;
@@ -163,14 +186,19 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
         m = (tid >> 3) + (M / 2) * (k / G8);
     };
     Vec16 idv[NID];
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(ident), 0, (int)((long)p.H * p.W * p.ldi * 2), 0x00020000);
     auto ident_fetch = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NID; ++k) {
             int m, icg;
             idmap(k, m, icg);
             const int y = ty0 + m / TW, x = tx0 + m % TW;
-            idv[k] = VEC16_ZERO;
-            if (y < p.H && x < p.W) idv[k] = *reinterpret_cast<const Vec16*>(ident + ((long)y * p.W + x) * p.ldi + icg);
+            int off = (y < p.H && x < p.W) ? ((y * p.W + x) * (int)p.ldi + icg) * 2 : OOB;
+#ifdef DCVC_DIAG
+            if (p.ablate & 32) off = (tid & 255) * 16;
+#endif
+            idv[k] = __builtin_bit_cast(Vec16, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0));
         }
     };
 
@@ -188,11 +216,6 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
                 const int hp = tid / GS + k * (NTHR / GS);
                 if (hp < HALO) *reinterpret_cast<Vec16*>(hb + hp * LDS_S + dcs) = pre[slab][k];
             }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) wtap[t] = wtap_n[t];
-            bd0 = bd0_n;
-            bd1 = bd1_n;
-            if (slab + 1 < nslab) taps_fetch(slab + 1);
             if (slab == nslab - 2) ident_fetch();   // (registers of the first slabs are free again; two slabs of time to arrive)
             if (slab == nslab - 1) {                // first turn of the weight ring: lands underneath the last slab
 #pragma unroll
@@ -201,6 +224,7 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
             if (slab == 0) STAMP(td[0]);
             __syncthreads();
             if (slab < 4) STAMP(td[1 + slab]);
+            taps_fetch(slab);
             const int c = slab * DW_SLAB + dcs;
             Vec16 tv[4][3];
 #pragma unroll
@@ -322,7 +346,7 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
     floatx16 ua[PTW], ub[PTW];
     // u accumulators start at the bias (lane's rows: quads 8 g + 4 hh of u_lo, then of u_hi): the first MFMA of a chain
     // takes the bias tuple as its C operand.  The bias of chunk j + 2 is requested during step j.
-    const float* b3w = p.b3 + 16 * cqw + 4 * hh;
+    const float* b3w = tabB3 + 16 * cqw + 4 * hh;       // (LDS copy)
     floatx16 biasv;
     auto bias_load = [&](int j) __attribute__((always_inline)) {
         j = j < NCH ? j : NCH - 1;

@@ -1053,6 +1053,7 @@ int launch_tail128(const TailParams& tp, int H, int W, hipStream_t st)
     static const bool want_stamps = getenv("DCVC_STAMPS") != nullptr;
     if (want_stamps) {
         TailParams q = tp;
+        q.ablate = getenv("DCVC_ABLATE") ? atoi(getenv("DCVC_ABLATE")) : 0;     // timing experiments (wrong results)
         DCVC_HIP(hipMalloc(&q.stamps, (size_t)grid * 16 * sizeof(unsigned long long)));
         hipLaunchKernelGGL((t128::dcb_tail128_kernel<C>), dim3(grid), dim3(t128::NTHR), lds, st, q);
         DCVC_HIP(hipStreamSynchronize(st));
