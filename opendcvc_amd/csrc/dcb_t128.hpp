@@ -202,6 +202,39 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
         }
     };
 
+    // LDS operand addresses of this lane: pixel row pl of this wave's pixel tile t (tile ph * PTW + t of the workgroup),
+    // k offset 8 hh
+    const int prow = (ph * PTW) * 32 + pl;
+    const half_t* xb = bufX + prow * LDX + 8 * hh;
+    auto bfrag_x = [&](int t, int s) __attribute__((always_inline)) {
+        return *reinterpret_cast<const half8*>(xb + t * 32 * LDX + s * 16);
+    };
+
+    // W2 d, one MFMA per slot.  (G2OV: the four k-steps (64 channels) of slab s - 1 issued between the multiply-adds of slab s
+    // of the depthwise stage - built, measured slower, switched off)
+    floatx16 acc[NTW][PTW];
+    half8 g2b[PTW];
+    auto gemm2_slot = [&](int s, int q) __attribute__((always_inline)) {      // MFMA q of k-step s of W2 d
+        const int i = q / PTW, t = q % PTW, k = (s * NTW + i) % D;
+        if (q == 0) {
+#pragma unroll
+            for (int tt = 0; tt < PTW; ++tt) g2b[tt] = bfrag_x(tt, s);
+        }
+        if (s == 0) {
+            floatx16 zero;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+            acc[i][t] = mfma32(ring[k], g2b[t], zero);
+        } else {
+            acc[i][t] = mfma32(ring[k], g2b[t], acc[i][t]);
+        }
+        if (t == PTW - 1) ring[k] = wload();
+    };
+    constexpr bool G2OV = false;                        // measured (C=256, 136x240): the depthwise slabs get slower by more than
+                                                        // W2's 3 K cycles (ring refills and fragment reads in a stage that
+                                                        // lives on its LDS / vector issue) - 45.0 us without, 45.8 us with
+    constexpr int G2Q = NTW * PTW;                      // MFMAs per k-step
+    constexpr int G2SLAB = (DW_SLAB / 16) * G2Q;        // MFMAs per slab (4 k-steps)
     // ---- depthwise 3x3 (zero padding) + bias -> d in bufX.  A slab goes registers -> one of two LDS halo buffers
     // (bufV region) -> taps; one barrier per slab.
     {
@@ -217,7 +250,7 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
                 if (hp < HALO) *reinterpret_cast<Vec16*>(hb + hp * LDS_S + dcs) = pre[slab][k];
             }
             if (slab == nslab - 2) ident_fetch();   // (registers of the first slabs are free again; two slabs of time to arrive)
-            if (slab == nslab - 1) {                // first turn of the weight ring: lands underneath the last slab
+            if (slab == (G2OV ? 0 : nslab - 1)) {   // first turn of the weight ring: lands underneath this slab
 #pragma unroll
                 for (int k = 0; k < D; ++k) ring[k] = wload();
             }
@@ -232,6 +265,7 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
                     tv[r][kx] = *reinterpret_cast<const Vec16*>(hb + ((py + r) * HW_ + px + kx) * LDS_S + dcs);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 float sacc[V];
@@ -240,7 +274,17 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) fma_vec16<half_t>(tv[e + ky][kx], wtap[ky * 3 + kx], sacc);
+                    for (int kx = 0; kx < 3; ++kx) {
+                        fma_vec16<half_t>(tv[e + ky][kx], wtap[ky * 3 + kx], sacc);
+                        // (18 tap groups per slab; the previous slab's W2 MFMAs spread over them)
+                        const int tg = e * 9 + ky * 3 + kx, m0 = tg * G2SLAB / 18, m1 = (tg + 1) * G2SLAB / 18;
+                        if (G2OV && slab > 0) {
+#pragma unroll
+                            for (int mm = 0; mm < G2SLAB; ++mm)
+                                if (mm >= m0 && mm < m1) gemm2_slot((slab - 1) * (DW_SLAB / 16) + mm / G2Q, mm % G2Q);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     sacc[j] = sacc[j] + bd0[j];
@@ -252,14 +296,6 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
         __syncthreads();
     }
     STAMP(ts1);
-
-    // LDS operand addresses of this lane: pixel row pl of this wave's pixel tile t (tile ph * PTW + t of the workgroup),
-    // k offset 8 hh
-    const int prow = (ph * PTW) * 32 + pl;
-    const half_t* xb = bufX + prow * LDX + 8 * hh;
-    auto bfrag_x = [&](int t, int s) __attribute__((always_inline)) {
-        return *reinterpret_cast<const half8*>(xb + t * 32 * LDX + s * 16);
-    };
 
     // output channel tile i of this wave = tile cqw + 4 i of the block (exists unless the width is ragged)
     auto tile_of = [&](int i) __attribute__((always_inline)) { return cqw + 4 * i; };
@@ -282,9 +318,16 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
     };
     ebias_load(p.b2);
 
-    // ---- GEMM2: W2 d (this wave's channel quarter x its 64 pixels)
-    floatx16 acc[NTW][PTW];
-    {
+    // ---- W2 d: the k-steps of the last slab (the others ran inside the depthwise stage), or all of them
+#pragma unroll
+    for (int mm = G2OV ? (nslab - 1) * G2SLAB : 0; mm < nslab * G2SLAB; ++mm) {
+        gemm2_slot(mm / G2Q, mm % G2Q);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- a C x C GEMM on the tile in bufX (this wave's channel quarter x its 64 pixels), weights through the ring in
+    // slots: the pixel fragments of k-step s + 1 are requested during k-step s.  Used for the fused next-block head / 1x1
+    // conv on r.  The ring must hold the stream's first D fragments; `next` supplies the following ones.
+    auto gemm_c = [&](auto next) __attribute__((always_inline)) {
         half8 bc[PTW], bn[PTW];
 #pragma unroll
         for (int t = 0; t < PTW; ++t) bc[t] = bfrag_x(t, 0);
@@ -299,13 +342,13 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
                 const int i = q / PTW, t = q % PTW, k = (s * NTW + i) % D;
                 if (s + 1 < KS && q < PTW) bn[q] = bfrag_x(q, s + 1);
                 acc[i][t] = mfma32(ring[k], bc[t], s == 0 ? zero : acc[i][t]);
-                if (t == PTW - 1) ring[k] = wload();
+                if (t == PTW - 1) ring[k] = next();
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int t = 0; t < PTW; ++t) bc[t] = bn[t];
         }
-    }
+    };
     STAMP(ts2);
     __syncthreads();   // every wave has finished reading d
     // (W2 d + b2) -> fp16 -> bufX
@@ -460,6 +503,22 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
 #undef T128_OFF
 
     STAMP(ts5);
+    // the fused next-block head / 1x1 conv (below): its first weight fragments are requested now, underneath the r epilogue
+    const bool fused_next = p.nwt != nullptr;
+    const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(fused_next ? p.nwt : p.wt)) + (size_t)cqw * (KS * NTW + D) * 1024, 0,
+        (KS * NTW + D) * 1024, 0x00020000);
+    int noff = 0;
+    auto nload = [&]() __attribute__((always_inline)) {
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(nrsrc, wlane, noff, 0);
+        noff += 1024;
+        return __builtin_bit_cast(half8, v);
+    };
+    if (fused_next) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) ring[k] = nload();
+    }
     // ---- r = (W4 v + b4) + o, in place in bufX (each element is owned by one lane)
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
@@ -522,43 +581,39 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
         o[13] = ts1 - td[4];    // last slab compute + barrier
     }
 #endif
-    if (p.nw1 != nullptr) {
-        // Fused head of the next block / fused 1x1 conv on the tile still in bufX: the 16x16x32 GEMM of gemm_core.hpp in
-        // the k order of dcb_head_kernel / conv_kernel, so the values are bit-identical to the separate launch.
-        constexpr int MT8 = M / 16, NT16 = (C / 16 + NW - 1) / NW;   // 16-channel tiles per wave (all 128 pixels)
-        constexpr bool RAG16 = (C / 16) % NW != 0;                    // (C = 320: 20 tiles on 8 waves - the waves without a
-        using frag_t = typename TR::frag_t;                           //  third tile run it on a clamped weight tile and drop it)
-        int tiles[NT16], wtiles[NT16];
-#pragma unroll
-        for (int i = 0; i < NT16; ++i) {
-            tiles[i] = wave + NW * i;
-            wtiles[i] = RAG16 ? min(tiles[i], C / 16 - 1) : tiles[i];
-        }
-        const int pl16 = lane & 15, cq = (lane >> 4) * 4;
-        floatx4 acc1[MT8][NT16];
-        zero_acc(acc1);
-        gemm_acc<half_t, MT8, NT16, 2>(acc1, bufX, LDX, C / KG, reinterpret_cast<const frag_t*>(p.nw1), C / KG, 0, wtiles, lane);
+    if (fused_next) {
+        // Fused head of the next block (a' = gate(W1' r + b1')) or fused 1x1 conv ((W r + b) [* q]) on the tile still in bufX
+        // (the host only fuses when this block has neither shortcut nor quant step: bufX holds exactly the values stored
+        // above).  Same 32x32x16 GEMM as W2, the weights as one more fragment stream per channel quarter.  An f16 MFMA
+        // accumulates its products in ascending k like a chain of fp32 additions whatever its shape, so the values equal
+        // dcb_head_kernel's / conv_kernel's 16x16x32 ones bit for bit (tests: chained == unchained).
+        gemm_c(nload);
         __syncthreads();   // every wave has finished reading r
 #pragma unroll
-        for (int i = 0; i < NT16; ++i) {
-            if (RAG16 && tiles[i] >= C / 16) continue;
-            const int ch0 = tiles[i] * 16 + cq;
-            const floatx4 bias = load_f4(p.nb1 + ch0);
-            floatx4 qv = {1.f, 1.f, 1.f, 1.f};
-            if (p.nplain && p.nq != nullptr) {
+        for (int i = 0; i < NTW; ++i) {
+            if (!tile_exists(i)) continue;
+            const int chb = 32 * tile_of(i) + 4 * hh;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) qv[r] = (ch0 + r) < p.n_log ? p.nq[ch0 + r] : 1.0f;
-            }
+            for (int g = 0; g < 4; ++g) {
+                const int ch0 = chb + 8 * g;
+                const floatx4 bias = load_f4(p.nb1 + ch0);
+                floatx4 qv = {1.f, 1.f, 1.f, 1.f};
+                if (p.nplain && p.nq != nullptr) {
 #pragma unroll
-            for (int m = 0; m < MT8; ++m) {
-                floatx4 v = acc1[m][i] + bias;
-                if (p.nplain) {
-                    if (p.nq != nullptr) v = v * qv;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = TR::gate(v[r]);
+                    for (int r = 0; r < 4; ++r) qv[r] = (ch0 + r) < p.n_log ? p.nq[ch0 + r] : 1.0f;
                 }
-                lds_store_quad<half_t>(bufX, LDX, m * 16 + pl16, ch0, v);
+#pragma unroll
+                for (int t = 0; t < PTW; ++t) {
+                    floatx4 v = {acc[i][t][4 * g], acc[i][t][4 * g + 1], acc[i][t][4 * g + 2], acc[i][t][4 * g + 3]};
+                    v = v + bias;
+                    if (p.nplain) {
+                        if (p.nq != nullptr) v = v * qv;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = TR::gate(v[r]);
+                    }
+                    lds_store_quad<half_t>(bufX, LDX, prow + 32 * t, ch0, v);
+                }
             }
         }
         __syncthreads();

@@ -227,7 +227,8 @@ struct TailParams {
     long ldhx;
     const void* hw1;
     const float* hb1;
-    const void* wt;      // dcb_tail128_kernel: the tail's weights as per-wave fragment streams (dcb_t128.hpp)
+    const void* wt;      // dcb_tail128_kernel: the tail's weights as per-quarter fragment streams (dcb_t128.hpp)
+    const void* nwt;     // ... and the fused next-block head's / 1x1 conv's (the same matrix as nw1, 32x32x16 fragments)
     int ablate;          // debug: bit0 skip dw, bit1 skip GEMM2, bit2 skip FFN GEMM3, bit3 skip FFN GEMM4
     unsigned long long* stamps;   // diagnostic build only (DCVC_STAMPS): 8 cycle counters per workgroup
 };
@@ -939,12 +940,14 @@ int upload_T(DevBuf& dst, int n, const std::function<float(int)>& get)
 struct dcvc_dcb {
     int dtype, cin, c, cin_p, c_p, shortcut, adapt;
     DevBuf wa, ba, w1, b1, wd, bd, w2, b2, w3, b3, w4, b4;
+    DevBuf w1_t128; // fp16, widths 256 / 320 / 384: W1 as a fragment stream (the previous block's tail computes this block's head)
     DevBuf wt128;   // fp16, widths 256 / 320 / 384: W2 | W3 | W4 once more as the fragment streams of dcb_tail128_kernel
 };
 
 struct dcvc_conv {
     int dtype, cin, cout, cin_p, n_p, cs_p, kh, kw, stride, pad, epi;
     DevBuf w, b;
+    DevBuf w_t128;  // square 1x1 convs of width 256 / 320 / 384, fp16: the fragment stream for a fused launch behind a 128-pixel tail
 };
 
 namespace {
@@ -1034,6 +1037,30 @@ int pack_t128(DevBuf& dst, const std::function<float(int, int)>& W2, const std::
 }
 
 inline bool t128_width_ok(int c_p) { return c_p == 256 || c_p == 320 || c_p == 384; }
+
+// a C x C matrix (next block's first conv, a fused 1x1 conv) as the per-quarter fragment stream gemm_c reads
+template <int C>
+int pack_t128_square(DevBuf& dst, const std::function<float(int, int)>& W)
+{
+    using CF = t128::Cfg<C>;
+    constexpr int LEN = CF::KS * CF::NTW + CF::D;
+    std::vector<half_t> buf((size_t)4 * LEN * 512, (half_t)0.f);
+    for (int cq = 0; cq < 4; ++cq) {
+        size_t f = 0;
+        for (int s = 0; s < CF::KS; ++s)
+            for (int i = 0; i < CF::NTW; ++i, ++f) {
+                half_t* o = &buf[((size_t)cq * LEN + f) * 512];
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) o[l * 8 + j] = (half_t)W(32 * (cq + 4 * i) + (l & 31), 16 * s + 8 * (l >> 5) + j);
+            }
+    }
+    return dst.upload(buf.data(), buf.size() * sizeof(half_t));
+}
+
+inline int pack_t128_square_any(int c_p, DevBuf& dst, const std::function<float(int, int)>& W)
+{
+    return c_p == 256 ? pack_t128_square<256>(dst, W) : c_p == 320 ? pack_t128_square<320>(dst, W) : pack_t128_square<384>(dst, W);
+}
 
 // DCVC_T128=0 keeps the 64-pixel tails on large maps (A/B measurements; both forms pass the same layer tests)
 static bool t128_enabled()
@@ -1211,8 +1238,10 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
 #endif
     if constexpr (sizeof(T) == 2 && MT == 4 && (NTW == 4 || NTW == 5 || NTW == 6)) {
         // large maps, widths 256 / 384: 128-pixel tiles, one 4-wave workgroup per CU, gate pipelined into the MFMA stream
-        if (h->wt128.p != nullptr && t128_enabled() && !head_in) {
+        const void* nwt = ch.next ? ch.next->w1_t128.p : ch.conv ? ch.conv->w_t128.p : nullptr;
+        if (h->wt128.p != nullptr && t128_enabled() && !head_in && (tp.nw1 == nullptr || nwt != nullptr)) {
             tp.wt = h->wt128.p;
+            tp.nwt = nwt;
             int rc = launch_tail128<NTW * 64>(tp, H, W, st);
             if (rc) return rc;
             DCVC_LAUNCH_CHECK();
@@ -1429,6 +1458,7 @@ int dcvc_dcb_create(int dtype, int cin, int c, int shortcut, const float* adapto
         auto W2 = [&](int n, int k) { return (n < C && k < C) ? w2[(size_t)n * C + k] : 0.f; };
         auto W3 = [&](int n, int k) { const int rr = u_row(n); return (rr >= 0 && k < C) ? ka * w3[(size_t)rr * C + k] : 0.f; };
         auto W4 = [&](int n, int k) { return (n < C && k < 2 * C) ? w4[(size_t)n * 2 * C + k] / ka : 0.f; };
+        rc |= pack_t128_square_any(Cp, h->w1_t128, [&](int n, int k) { return (n < C && k < C) ? ka * w1[(size_t)n * C + k] : 0.f; });
         rc |= Cp == 256 ? pack_t128<256>(h->wt128, W2, W3, W4)
                         : Cp == 320 ? pack_t128<320>(h->wt128, W2, W3, W4) : pack_t128<384>(h->wt128, W2, W3, W4);
     }
@@ -1608,6 +1638,8 @@ int dcvc_conv_create(int dtype, int cin, int cout, int kh, int kw, int stride, i
         return (nl >= 0 && ci < cin) ? w[((size_t)nl * cin + ci) * taps + t] : 0.f;
     });
     rc |= upload_f32(h->b, Np, [&](int n) { const int nl = to_log(n); return nl >= 0 ? b[nl] : 0.f; });
+    if (rc == 0 && dtype == DCVC_F16 && taps == 1 && epilogue != DCVC_EPI_SHUFFLE2 && Np == Kp && Np == round_up(cout, 64) && t128_width_ok(Np))
+        rc |= pack_t128_square_any(Np, h->w_t128, [&](int n, int k) { return (n < cout && k < cin) ? w[(size_t)n * cin + k] : 0.f; });
     if (rc) return rc < 0 ? rc : dcvc::E_MEM;
     *out = h.release();
     return 0;
