@@ -629,4 +629,206 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// DepthConvBlock head for large maps, 128-pixel tiles (the dcb_head_kernel of dcvc_nn.hip in the form of the tail above):
+//   x (one or two sources) -> [x' = Wa x + ba -> identity out] -> a = gate(W1 x' + b1)
+// 8 waves = (channel quarter, pixel half), 32x32x16 MFMAs, each matrix as a per-quarter fragment stream through a register
+// ring (wa128: Kin / 16 k-steps, source 0's channels first; w1128: the stream a fused-head tail uses).  The sources pass
+// through LDS in chunks of up to 128 channels (the next chunk's loads are in flight during the current chunk's MFMAs), k
+// ascending across chunks and sources: the accumulation order of the one-pass form, so the values equal dcb_head_kernel's
+// bit for bit.  One workgroup per CU (a 1080p map has 255 tiles): 512 registers per lane.
+template <int C>
+struct HeadCfg {
+    using CF = Cfg<C>;
+    static constexpr int DH = 4 * CF::NTW;          // ring depth = the fragments of 4 k-steps (64 input channels)
+    static constexpr int KCH = 128;                 // channels per staged chunk
+    static constexpr int LDS_S = KCH + PAD;
+    static constexpr size_t LDS = ((size_t)M * LDS_S + (size_t)M * CF::LDX) * sizeof(half_t);
+};
+
+template <int C, bool ADAPT>
+__global__ __launch_bounds__(NTHR, 1) void dcb_head128_kernel(HeadParams p)
+{
+    using TR = Traits<half_t>;
+    using CF = Cfg<C>;
+    using HC = HeadCfg<C>;
+    constexpr int NTW = CF::NTW, KS = CF::KS, LDX = CF::LDX, V = 8, DH = HC::DH, KCH = HC::KCH, LDS_S = HC::LDS_S, G8 = C / 64;
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    half_t* bufY = reinterpret_cast<half_t*>(smem);        // x' (the W1 GEMM's operand), then the output tile
+    half_t* bufS = bufY + M * LDX;                          // the staged source chunk
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cqw = wave & 3, ph = wave >> 2;
+    const int pl = lane & 31, hh = lane >> 5;
+    const int tiles_x = (p.W + TW - 1) / TW;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const int prow = (ph * PTW) * 32 + pl;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int OOB = 0x7FFFFFF0;
+    auto tile_of = [&](int i) __attribute__((always_inline)) { return cqw + 4 * i; };
+    auto tile_exists = [&](int i) __attribute__((always_inline)) { return !CF::RAG || cqw + 4 * i < CF::NT; };
+
+    // the two pixels this thread stages / stores (rows tid / 8 and tid / 8 + 64 of the tile): index in the picture or -1
+    int pix2[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int m = (tid >> 3) + (M / 2) * k;
+        const int y = ty0 + m / TW, x = tx0 + m % TW;
+        pix2[k] = (y < p.H && x < p.W) ? y * p.W + x : -1;
+    }
+    // fragment streams: offsets in a vector register, so a read past the stream's end is range-checked to zero
+    auto make_stream = [&](const void* base, int frags) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(base)) + (size_t)cqw * (frags + CF::D) * 1024, 0, (frags + CF::D) * 1024,
+            0x00020000);
+    };
+    floatx16 acc[NTW][PTW];
+    half8 ring[DH];
+    auto zero_all = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int t = 0; t < PTW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+    };
+    // acc += (64 nb input channels of the tile in X, row stride ldx) x (the stream's next 4 nb k-steps); the ring holds the
+    // first DH fragments on entry and the following DH on exit
+    auto gemm = [&](const half_t* X, int ldx, int nb, auto next) __attribute__((always_inline)) {
+        const half_t* xb = X + prow * ldx + 8 * hh;
+        half8 bc[PTW], bn[PTW];
+#pragma unroll
+        for (int t = 0; t < PTW; ++t) bc[t] = *reinterpret_cast<const half8*>(xb + t * 32 * ldx);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int b = 0; b < nb; ++b) {
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss) {
+                const int sn = (ss < 3 || b + 1 < nb) ? 4 * b + ss + 1 : 4 * b + ss;
+#pragma unroll
+                for (int q = 0; q < NTW * PTW; ++q) {
+                    const int i = q / PTW, t = q % PTW, k = ss * NTW + i;
+                    if (q < PTW) bn[q] = *reinterpret_cast<const half8*>(xb + q * 32 * ldx + sn * 16);
+                    acc[i][t] = mfma32(ring[k], bc[t], acc[i][t]);
+                    if (t == PTW - 1) ring[k] = next();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int t = 0; t < PTW; ++t) bc[t] = bn[t];
+            }
+        }
+    };
+    // coalesced store of the [128][C] tile in bufY to a tensor with row stride ldg
+    auto store_tile = [&](void* g, long ldg) __attribute__((always_inline)) {
+        half_t* gp = reinterpret_cast<half_t*>(g);
+#pragma unroll
+        for (int k = 0; k < 2 * G8; ++k) {
+            const int m = (tid >> 3) + (M / 2) * (k / G8), c = ((tid & 7) + 8 * (k % G8)) * V;
+            const int px = pix2[k / G8];
+            if (px >= 0) *reinterpret_cast<Vec16*>(gp + (long)px * ldg + c) = *reinterpret_cast<const Vec16*>(bufY + m * LDX + c);
+        }
+    };
+    // acc + bias [-> gate] -> fp16 -> bufY
+    auto epilogue = [&](const float* bias_p, bool gate) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            if (!tile_exists(i)) continue;
+            const int chb = 32 * tile_of(i) + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const floatx4 bias = load_f4(bias_p + chb + 8 * g);
+#pragma unroll
+                for (int t = 0; t < PTW; ++t) {
+                    floatx4 v = {acc[i][t][4 * g], acc[i][t][4 * g + 1], acc[i][t][4 * g + 2], acc[i][t][4 * g + 3]};
+                    v = v + bias;
+                    if (gate) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = TR::gate(v[r]);
+                    }
+                    lds_store_quad<half_t>(bufY, LDX, prow + 32 * t, chb + 8 * g, v);
+                }
+            }
+        }
+    };
+
+    const __amdgpu_buffer_rsrc_t wrs = make_stream(p.w1128, KS * NTW);
+    int woff = lane * 16;
+    auto wnext = [&]() __attribute__((always_inline)) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, woff, 0, 0);
+        woff += 1024;
+        return __builtin_bit_cast(half8, v);
+    };
+    zero_all();
+    if constexpr (ADAPT) {
+        const int Kin = p.src.c0 + p.src.c1;
+        const __amdgpu_buffer_rsrc_t ars = make_stream(p.wa128, (Kin / 16) * NTW);
+        int aoff = lane * 16;
+        auto anext = [&]() __attribute__((always_inline)) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ars, aoff, 0, 0);
+            aoff += 1024;
+            return __builtin_bit_cast(half8, v);
+        };
+        const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(p.src.x0), 0, (int)((long)p.H * p.W * p.src.ld0 * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(p.src.c1 > 0 ? p.src.x1 : p.src.x0), 0, (int)((long)p.H * p.W * (p.src.c1 > 0 ? p.src.ld1 : p.src.ld0) * 2),
+            0x00020000);
+        const int n0 = (p.src.c0 + KCH - 1) / KCH, nchunk = n0 + (p.src.c1 + KCH - 1) / KCH;
+        // chunk i: KCH channels (the last chunk of a source may hold 64) -> registers; returns its channel count
+        u32x4 pre[4];
+        auto fetch = [&](int i) __attribute__((always_inline)) {
+            const bool s1 = i >= n0;
+            const int cb = (s1 ? i - n0 : i) * KCH;
+            const int left = (s1 ? p.src.c1 : p.src.c0) - cb, cnt = left < KCH ? left : KCH;
+            const int ld = (int)(s1 ? p.src.ld1 : p.src.ld0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = ((tid & 7) + 8 * (k & 1)) * V, px = pix2[k >> 1];
+                const int off = (px >= 0 && c < cnt) ? (px * ld + cb + c) * 2 : OOB;
+                pre[k] = s1 ? __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0);
+            }
+            return cnt;
+        };
+        int cnt = fetch(0);
+#pragma unroll
+        for (int k = 0; k < DH; ++k) ring[k] = anext();
+        for (int i = 0; i < nchunk; ++i) {
+            if (i > 0) __syncthreads();      // every wave has finished reading the previous chunk
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                *reinterpret_cast<u32x4*>(bufS + ((tid >> 3) + (M / 2) * (k >> 1)) * LDS_S + ((tid & 7) + 8 * (k & 1)) * V) = pre[k];
+            const int cur = cnt;
+            __syncthreads();
+            if (i + 1 < nchunk) cnt = fetch(i + 1);
+            gemm(bufS, LDS_S, cur / 64, anext);
+        }
+        // W1's first fragments are requested now; x' = Wa x + ba -> bufY, and out as the block's identity branch
+#pragma unroll
+        for (int k = 0; k < DH; ++k) ring[k] = wnext();
+        epilogue(p.ba, false);
+        __syncthreads();
+        store_tile(p.ident, p.ldi);
+        zero_all();
+    } else {
+        const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(p.src.x0), 0, (int)((long)p.H * p.W * p.src.ld0 * 2), 0x00020000);
+        u32x4 xin[2 * G8];
+#pragma unroll
+        for (int k = 0; k < 2 * G8; ++k) {
+            const int c = ((tid & 7) + 8 * (k % G8)) * V, px = pix2[k / G8];
+            xin[k] = __builtin_amdgcn_raw_buffer_load_b128(rs0, px >= 0 ? (px * (int)p.src.ld0 + c) * 2 : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < DH; ++k) ring[k] = wnext();
+#pragma unroll
+        for (int k = 0; k < 2 * G8; ++k)
+            *reinterpret_cast<u32x4*>(bufY + ((tid >> 3) + (M / 2) * (k / G8)) * LDX + ((tid & 7) + 8 * (k % G8)) * V) = xin[k];
+        __syncthreads();
+    }
+    gemm(bufY, LDX, KS / 4, wnext);
+    __syncthreads();       // every wave has finished reading x': the output tile replaces it
+    epilogue(p.b1, true);
+    __syncthreads();
+    store_tile(p.a_out, p.lda);
+}
+
 }  // namespace t128

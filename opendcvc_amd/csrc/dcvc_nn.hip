@@ -89,6 +89,8 @@ struct HeadParams {
     void* a_out;
     long lda;
     int split;     // adaptor over two sources: stage and reduce one source at a time (half the LDS, same k order)
+    const void* wa128;   // dcb_head128_kernel: adaptor / first conv as per-quarter fragment streams (dcb_t128.hpp)
+    const void* w1128;
 };
 
 template <typename T, int MT, int NTW, bool ADAPT>
@@ -940,6 +942,7 @@ int upload_T(DevBuf& dst, int n, const std::function<float(int)>& get)
 struct dcvc_dcb {
     int dtype, cin, c, cin_p, c_p, shortcut, adapt;
     DevBuf wa, ba, w1, b1, wd, bd, w2, b2, w3, b3, w4, b4;
+    DevBuf wa_t128; // fp16, widths 256 / 320 / 384: the adaptor as a fragment stream (dcb_head128_kernel)
     DevBuf w1_t128; // fp16, widths 256 / 320 / 384: W1 as a fragment stream (the previous block's tail computes this block's head)
     DevBuf wt128;   // fp16, widths 256 / 320 / 384: W2 | W3 | W4 once more as the fragment streams of dcb_tail128_kernel
 };
@@ -1057,6 +1060,25 @@ int pack_t128_square(DevBuf& dst, const std::function<float(int, int)>& W)
     return dst.upload(buf.data(), buf.size() * sizeof(half_t));
 }
 
+// a C x K matrix (the adaptor: K = padded input channels) in the same form: K / 16 k-steps
+template <int C>
+int pack_t128_rect(DevBuf& dst, int Kp, const std::function<float(int, int)>& W)
+{
+    using CF = t128::Cfg<C>;
+    const int ks = Kp / 16, LEN = ks * CF::NTW + CF::D;
+    std::vector<half_t> buf((size_t)4 * LEN * 512, (half_t)0.f);
+    for (int cq = 0; cq < 4; ++cq) {
+        size_t f = 0;
+        for (int s = 0; s < ks; ++s)
+            for (int i = 0; i < CF::NTW; ++i, ++f) {
+                half_t* o = &buf[((size_t)cq * LEN + f) * 512];
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) o[l * 8 + j] = (half_t)W(32 * (cq + 4 * i) + (l & 31), 16 * s + 8 * (l >> 5) + j);
+            }
+    }
+    return dst.upload(buf.data(), buf.size() * sizeof(half_t));
+}
+
 inline int pack_t128_square_any(int c_p, DevBuf& dst, const std::function<float(int, int)>& W)
 {
     return c_p == 256 ? pack_t128_square<256>(dst, W) : c_p == 320 ? pack_t128_square<320>(dst, W) : pack_t128_square<384>(dst, W);
@@ -1066,6 +1088,12 @@ inline int pack_t128_square_any(int c_p, DevBuf& dst, const std::function<float(
 static bool t128_enabled()
 {
     static const bool on = !(getenv("DCVC_T128") && atoi(getenv("DCVC_T128")) == 0);
+    return on;
+}
+
+static bool h128_enabled()   // DCVC_H128=0: large-map heads by dcb_head_kernel (A/B measurements, bit-identity checks)
+{
+    static const bool on = !(getenv("DCVC_H128") && atoi(getenv("DCVC_H128")) == 0);
     return on;
 }
 
@@ -1153,8 +1181,31 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     constexpr bool kHeadInKernel = sizeof(T) == 2 && MT == 2 && (NTW <= 4 || NTW == 6);   // (6: the 8-wave tail of C=384)
     const bool head_in = kHeadInKernel && !ch.head_done && !ch.separate_head && !h->adapt && src.c1 == 0;
     if (ev) DCVC_HIP(hipEventRecord(ev[0], st));
-    if (ch.head_done || head_in) {
-        // `a` was written by the previous block's tail / is computed by this block's tail
+    // large maps, widths 256 / 320 / 384: the 128-pixel head (sources of 64-channel multiples, at most 256 channels each)
+    bool head128 = false;
+    if constexpr (sizeof(T) == 2 && MT == 4 && (NTW == 4 || NTW == 5 || NTW == 6)) {
+        head128 = t128_enabled() && h128_enabled() && !ch.head_done && !head_in && h->w1_t128.p != nullptr &&
+                  (h->adapt ? (h->wa_t128.p != nullptr && src.c0 % 64 == 0 && src.c1 % 64 == 0 && kin == h->cin_p)
+                            : (src.c1 == 0 && src.c0 == NTW * 64));
+        if (head128) {
+            hp.wa128 = h->wa_t128.p;
+            hp.w1128 = h->w1_t128.p;
+            const int g128 = ((H + t128::TH - 1) / t128::TH) * ((W + t128::TW - 1) / t128::TW);
+            const size_t lds = t128::HeadCfg<NTW * 64>::LDS;
+            int rc;
+            if (h->adapt) {
+                rc = set_lds(t128::dcb_head128_kernel<NTW * 64, true>, lds);
+                if (rc) return rc;
+                hipLaunchKernelGGL((t128::dcb_head128_kernel<NTW * 64, true>), dim3(g128), dim3(t128::NTHR), lds, st, hp);
+            } else {
+                rc = set_lds(t128::dcb_head128_kernel<NTW * 64, false>, lds);
+                if (rc) return rc;
+                hipLaunchKernelGGL((t128::dcb_head128_kernel<NTW * 64, false>), dim3(g128), dim3(t128::NTHR), lds, st, hp);
+            }
+        }
+    }
+    if (ch.head_done || head_in || head128) {
+        // `a` was written by the previous block's tail / is computed by this block's tail / by the 128-pixel head
     } else if (h->adapt) {
         // two sources: one at a time through LDS (half the staging buffer: a 64-pixel tile of 256 + 256 channels then
         // leaves room for two workgroups per CU, i.e. half the weight fragments per pixel of the 32-pixel form)
@@ -1458,6 +1509,11 @@ int dcvc_dcb_create(int dtype, int cin, int c, int shortcut, const float* adapto
         auto W2 = [&](int n, int k) { return (n < C && k < C) ? w2[(size_t)n * C + k] : 0.f; };
         auto W3 = [&](int n, int k) { const int rr = u_row(n); return (rr >= 0 && k < C) ? ka * w3[(size_t)rr * C + k] : 0.f; };
         auto W4 = [&](int n, int k) { return (n < C && k < 2 * C) ? w4[(size_t)n * 2 * C + k] / ka : 0.f; };
+        if (h->adapt && Kp % 64 == 0) {
+            auto WA = [&](int n, int k) { return (n < C && k < cin) ? adaptor_w[(size_t)n * cin + k] : 0.f; };
+            rc |= Cp == 256 ? pack_t128_rect<256>(h->wa_t128, Kp, WA) : Cp == 320 ? pack_t128_rect<320>(h->wa_t128, Kp, WA)
+                                                                                 : pack_t128_rect<384>(h->wa_t128, Kp, WA);
+        }
         rc |= pack_t128_square_any(Cp, h->w1_t128, [&](int n, int k) { return (n < C && k < C) ? ka * w1[(size_t)n * C + k] : 0.f; });
         rc |= Cp == 256 ? pack_t128<256>(h->wt128, W2, W3, W4)
                         : Cp == 320 ? pack_t128<320>(h->wt128, W2, W3, W4) : pack_t128<384>(h->wt128, W2, W3, W4);

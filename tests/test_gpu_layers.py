@@ -126,6 +126,49 @@ def test_depth_conv_block_large_map_fp16(c):
     compare(got[:, :, :c], ref, torch.float16, f"dcb large map c={c}")
 
 
+ADAPTOR_LARGE = [(192, 256, 256), (256, 256, 256), (64, 0, 256), (256, 0, 320), (192, 0, 368), (320, 256, 384), (128, 192, 320)]
+
+
+def _adaptor_block_large(cin0, cin1, c, H=101, W=123):
+    from opendcvc_amd import nn
+    rng = _rng(500 + cin0 + 3 * cin1 + 7 * c)
+    cin = cin0 + cin1
+    sd = make_dcb_weights(rng, "m", cin, c, True)
+    x = rng.standard_normal((H, W, cin)).astype(np.float16).astype(np.float32)
+    blk = nn.DepthConvBlock(sd, "m", torch.float16)
+    x0 = to_dev(x[:, :, :cin0], cin0, torch.float16)
+    out = blk(x0, to_dev(x[:, :, cin0:], cin1, torch.float16)) if cin1 else blk(x0)
+    torch.cuda.synchronize()
+    return sd, x, out.float().cpu().numpy()
+
+
+@pytest.mark.parametrize("cin0,cin1,c", ADAPTOR_LARGE)
+def test_adaptor_block_large_map_fp16(cin0, cin1, c):
+    """Adaptor blocks (one or two sources) on a large map: the 128-pixel head (dcb_head128_kernel: sources through LDS in
+    128-channel chunks, 64-channel remainders, ragged width 320, edge tiles) in front of the 128-pixel tail."""
+    sd, x, got = _adaptor_block_large(cin0, cin1, c)
+    ref = O.Net(sd).dcb_f16(x, "m", shortcut=False, q=None)
+    assert not np.any(got[:, :, c:]), "pad channels must stay zero"
+    compare(got[:, :, :c], ref, torch.float16, f"adaptor block large map {cin0}+{cin1}->{c}")
+
+
+def test_head128_equals_head64_bitwise(tmp_path):
+    """The 128-pixel head accumulates in the same k order as dcb_head_kernel: identical block outputs with DCVC_H128=0
+    (a separate process: the switch is read once)."""
+    import os, subprocess, sys
+    outs = {}
+    for v in ("1", "0"):
+        path = tmp_path / f"o{v}.npy"
+        here = os.path.dirname(os.path.abspath(__file__))
+        code = ("import sys, numpy as np; sys.path[:0] = [%r, %r, %r]; import test_gpu_layers as t; "
+                "np.save(%r, np.concatenate([t._adaptor_block_large(192, 256, 256)[2].ravel(), "
+                "t._adaptor_block_large(256, 0, 320)[2].ravel()]))"
+                % (here, os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), str(path)))
+        subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, DCVC_H128=v))
+        outs[v] = np.load(path)
+    assert np.array_equal(outs["1"], outs["0"])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("c,hw", [(256, (21, 19)), (128, (9, 33)), (368, (12, 11)), (320, (101, 123)), (256, (101, 123)), (368, (99, 125))])
 def test_chained_blocks_equal_separate_calls(c, hw, dtype):
