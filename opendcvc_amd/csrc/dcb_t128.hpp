@@ -831,4 +831,158 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_head128_kernel(HeadParams p)
     store_tile(p.a_out, p.lda);
 }
 
+// ------------------------------------------------------------------------------------------
+// 3x3 convolution (stride 1, zero padding 1, one source) as an implicit GEMM in the same form: a workgroup owns a 128-pixel
+// tile x a slice of 256 output channels (blockIdx.y), the input tile + 1-pixel halo sits in LDS once and the nine taps read it
+// at shifted rows; the slice's weights are one fragment stream per channel quarter in (tap, k-step, tile) order.  Written
+// for decoder.up at 68x120 (128 -> 4 x 256, 2.4 MB of weights): with 32-pixel tiles every CU streamed all of them, here a
+// CU streams one slice.  Accumulation order = conv_kernel's (tap major, k ascending): the same values bit for bit.
+// Epilogue: + bias, plain or PixelShuffle(2) (a slice lies inside one sub-pixel phase: cs_p % 256 == 0).
+struct Conv128Params {
+    const void* x;
+    long ldx;
+    int H, W, kin;
+    const void* wt;       // [slice][quarter][9 * kin / 16 * 2 + D] fragments of 1 KiB
+    const float* b;
+    void* out;
+    long ldo;
+    int shuffle, cs_p;
+};
+
+// NTW = channel tiles per wave: output slices of 128 NTW channels.  NTW = 2: one workgroup per CU (used when the grid then
+// fits the chip in one round); NTW = 1: 128 registers, two workgroups per CU (finer work items for grids in between).
+// The output tile replaces the input tile in LDS.
+inline size_t conv128_lds(int kin, int ntw)
+{
+    const size_t in = (size_t)HALO * (kin + PAD), out = (size_t)M * (128 * ntw + PAD);
+    return (in > out ? in : out) * sizeof(half_t);
+}
+
+template <int NTW>
+__global__ __launch_bounds__(NTHR, NTW == 1 ? 4 : 2) void conv3x3_t128_kernel(Conv128Params p)
+{
+    constexpr int CONV_SLICE = 128 * NTW, DH = 4 * NTW, V = 8, LDO = CONV_SLICE + PAD, HW_ = TW + 2, G8 = CONV_SLICE / 64;
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    const int lds_s = p.kin + PAD;
+    half_t* bufS = reinterpret_cast<half_t*>(smem);          // input tile + halo, rows lds_s apart
+    half_t* bufO = bufS;                                      // ... then the output tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cqw = wave & 3, ph = wave >> 2;
+    const int pl = lane & 31, hh = lane >> 5;
+    const int tiles_x = (p.W + TW - 1) / TW;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const int slice = blockIdx.y;
+    const int prow = (ph * PTW) * 32 + pl;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int OOB = 0x7FFFFFF0;
+    const int ksteps = p.kin / 16, frags = 9 * ksteps * NTW;
+
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.wt)) + ((size_t)slice * 4 + cqw) * (frags + DH) * 1024, 0, (frags + DH) * 1024,
+        0x00020000);
+    int woff = lane * 16;
+    auto wnext = [&]() __attribute__((always_inline)) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, woff, 0, 0);
+        woff += 1024;
+        return __builtin_bit_cast(half8, v);
+    };
+    // input tile + halo -> LDS (pixels outside the picture read zeros: the padding)
+    {
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(p.x), 0, (int)((long)p.H * p.W * p.ldx * 2), 0x00020000);
+        const int G = p.kin / V, total = HALO * G;
+        constexpr int U = 6;
+        for (int it0 = tid; it0 < total; it0 += U * NTHR) {
+            u32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int it = it0 + u * NTHR, hp = it / G, c = (it - hp * G) * V;
+                const int y = ty0 - 1 + hp / HW_, x = tx0 - 1 + hp % HW_;
+                const bool ok = it < total && y >= 0 && y < p.H && x >= 0 && x < p.W;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? ((y * p.W + x) * (int)p.ldx + c) * 2 : OOB, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int it = it0 + u * NTHR, hp = it / G, c = (it - hp * G) * V;
+                if (it < total) *reinterpret_cast<u32x4*>(bufS + hp * lds_s + c) = v[u];
+            }
+        }
+    }
+    half8 ring[DH];
+#pragma unroll
+    for (int k = 0; k < DH; ++k) ring[k] = wnext();
+    floatx16 acc[NTW][PTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int t = 0; t < PTW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+    __syncthreads();
+
+    // B operand of pixel tile t at tap (ky, kx), k-step s: halo row ((py + ky) * 18 + px + kx), columns 16 s + 8 hh
+    const half_t* xb[PTW];
+#pragma unroll
+    for (int t = 0; t < PTW; ++t) {
+        const int m = prow + 32 * t;
+        xb[t] = bufS + ((m / TW) * HW_ + m % TW) * lds_s + 8 * hh;
+    }
+    const int nb = p.kin / 64;                   // bodies of 4 k-steps per tap
+    half8 bc[PTW], bn[PTW];
+#pragma unroll
+    for (int t = 0; t < PTW; ++t) bc[t] = *reinterpret_cast<const half8*>(xb[t]);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int tap = 0; tap < 9; ++tap) {
+        const int toff = ((tap / 3) * HW_ + tap % 3) * lds_s;
+        const int tnext = (((tap + 1) / 3) * HW_ + (tap + 1) % 3) * lds_s;
+        for (int b = 0; b < nb; ++b) {
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss) {
+                // operand of the next k-step: the same tap, or the next tap's first (the very last step re-reads its own)
+                int noff = toff + (4 * b + ss + 1) * 16;
+                if (ss == 3 && b + 1 == nb) noff = tap < 8 ? tnext : toff + (4 * b + ss) * 16;
+#pragma unroll
+                for (int q = 0; q < NTW * PTW; ++q) {
+                    const int i = q / PTW, t = q % PTW, k = ss * NTW + i;
+                    if (q < PTW) bn[q] = *reinterpret_cast<const half8*>(xb[q] + noff);
+                    acc[i][t] = mfma32(ring[k], bc[t], acc[i][t]);
+                    if (t == PTW - 1) ring[k] = wnext();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int t = 0; t < PTW; ++t) bc[t] = bn[t];
+            }
+        }
+    }
+    __syncthreads();      // every wave has finished reading the input tile
+    // + bias -> fp16 -> output tile in LDS -> coalesced rows
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int chb = 32 * (cqw + 4 * i) + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const floatx4 bias = load_f4(p.b + slice * CONV_SLICE + chb + 8 * g);
+#pragma unroll
+            for (int t = 0; t < PTW; ++t) {
+                floatx4 v = {acc[i][t][4 * g], acc[i][t][4 * g + 1], acc[i][t][4 * g + 2], acc[i][t][4 * g + 3]};
+                lds_store_quad<half_t>(bufO, LDO, prow + 32 * t, chb + 8 * g, v + bias);
+            }
+        }
+    }
+    __syncthreads();
+    half_t* out = reinterpret_cast<half_t*>(p.out);
+    const int n0 = slice * CONV_SLICE;
+    const int sp = p.shuffle ? n0 / p.cs_p : 0, sch0 = p.shuffle ? n0 - sp * p.cs_p : n0;
+#pragma unroll
+    for (int k = 0; k < 2 * G8; ++k) {
+        const int m = (tid >> 3) + (M / 2) * (k / G8), c = ((tid & 7) + 8 * (k % G8)) * V;
+        const int oy = ty0 + m / TW, ox = tx0 + m % TW;
+        if (oy < p.H && ox < p.W) {
+            const long pix = p.shuffle ? (long)(2 * oy + (sp >> 1)) * (2 * p.W) + (2 * ox + (sp & 1)) : (long)oy * p.W + ox;
+            *reinterpret_cast<Vec16*>(out + pix * p.ldo + sch0 + c) = *reinterpret_cast<const Vec16*>(bufO + m * LDO + c);
+        }
+    }
+}
+
 }  // namespace t128

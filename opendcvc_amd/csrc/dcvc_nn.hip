@@ -951,6 +951,7 @@ struct dcvc_conv {
     int dtype, cin, cout, cin_p, n_p, cs_p, kh, kw, stride, pad, epi;
     DevBuf w, b;
     DevBuf w_t128;  // square 1x1 convs of width 256 / 320 / 384, fp16: the fragment stream for a fused launch behind a 128-pixel tail
+    DevBuf w_c128[2];   // fp16, 3x3 s1 p1 convs: fragment streams of conv3x3_t128_kernel<1> (128-channel slices) and <2> (256)
 };
 
 namespace {
@@ -1076,6 +1077,27 @@ int pack_t128_rect(DevBuf& dst, int Kp, const std::function<float(int, int)>& W)
                     for (int j = 0; j < 8; ++j) o[l * 8 + j] = (half_t)W(32 * (cq + 4 * i) + (l & 31), 16 * s + 8 * (l >> 5) + j);
             }
     }
+    return dst.upload(buf.data(), buf.size() * sizeof(half_t));
+}
+
+// 3x3 conv, Np / (128 ntw) slices x 4 quarters: fragments in (tap, k-step, tile) order; W(n, tap, ci) = physical row n
+inline int pack_t128_conv3x3(DevBuf& dst, int ntw, int Np, int Kp, const std::function<float(int, int, int)>& W)
+{
+    const int DH = 4 * ntw, slice = 128 * ntw;
+    const int ks = Kp / 16, LEN = 9 * ks * ntw + DH, nsl = Np / slice;
+    std::vector<half_t> buf((size_t)nsl * 4 * LEN * 512, (half_t)0.f);
+    for (int sl = 0; sl < nsl; ++sl)
+        for (int cq = 0; cq < 4; ++cq) {
+            size_t f = 0;
+            for (int tap = 0; tap < 9; ++tap)
+                for (int s = 0; s < ks; ++s)
+                    for (int i = 0; i < ntw; ++i, ++f) {
+                        half_t* o = &buf[(((size_t)sl * 4 + cq) * LEN + f) * 512];
+                        for (int l = 0; l < 64; ++l)
+                            for (int j = 0; j < 8; ++j)
+                                o[l * 8 + j] = (half_t)W(sl * slice + 32 * (cq + 4 * i) + (l & 31), tap, 16 * s + 8 * (l >> 5) + j);
+                    }
+        }
     return dst.upload(buf.data(), buf.size() * sizeof(half_t));
 }
 
@@ -1453,10 +1475,49 @@ static int run_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const fl
     }
 }
 
+static bool c128_enabled()   // DCVC_C128=0: 3x3 convs by conv_kernel (A/B measurements, bit-identity checks)
+{
+    static const bool on = !(getenv("DCVC_C128") && atoi(getenv("DCVC_C128")) == 0);
+    return on;
+}
+
 static int run_conv(const dcvc_conv* h, const ConvParams& cp, hipStream_t st)
 {
     if (h->dtype != DCVC_F16) return dispatch_conv<float, 2>(h, cp, st);
+    if (h->w_c128[0].p != nullptr && c128_enabled() && cp.src.c1 == 0 && cp.in_q == nullptr) {
+        const int tiles = ((cp.H + t128::TH - 1) / t128::TH) * ((cp.W + t128::TW - 1) / t128::TW);
+        // 256-channel slices at one workgroup per CU if that grid runs in one round, else 128-channel slices at two per CU
+        const int ntw = tiles * (cp.N / 256) <= 256 ? 2 : 1;
+        t128::Conv128Params p{};
+        p.x = cp.src.x0;
+        p.ldx = cp.src.ld0;
+        p.H = cp.H;
+        p.W = cp.W;
+        p.kin = cp.src.c0;
+        p.wt = h->w_c128[ntw - 1].p;
+        p.b = cp.b;
+        p.out = cp.out;
+        p.ldo = cp.ldo;
+        p.shuffle = cp.epi == DCVC_EPI_SHUFFLE2;
+        p.cs_p = cp.cs_p;
+        const size_t lds = t128::conv128_lds(p.kin, ntw);
+        const dim3 g(tiles, cp.N / (128 * ntw));
+        int rc = ntw == 2 ? set_lds(t128::conv3x3_t128_kernel<2>, lds) : set_lds(t128::conv3x3_t128_kernel<1>, lds);
+        if (rc) return rc;
+        if (ntw == 2)
+            hipLaunchKernelGGL(t128::conv3x3_t128_kernel<2>, g, dim3(t128::NTHR), lds, st, p);
+        else
+            hipLaunchKernelGGL(t128::conv3x3_t128_kernel<1>, g, dim3(t128::NTHR), lds, st, p);
+        DCVC_LAUNCH_CHECK();
+        return 0;
+    }
     const long P = (long)cp.Ho * cp.Wo;
+#ifdef DCVC_DIAG
+    static const int forced = getenv("DCVC_CONV_MT") ? atoi(getenv("DCVC_CONV_MT")) : 0;
+    if (forced == 2) return dispatch_conv<half_t, 2>(h, cp, st);
+    if (forced == 4) return dispatch_conv<half_t, 4>(h, cp, st);
+    if (forced == 8) return dispatch_conv<half_t, 8>(h, cp, st);
+#endif
     if (P >= 12000) return dispatch_conv<half_t, 4>(h, cp, st);
     return dispatch_conv<half_t, 2>(h, cp, st);
 }
@@ -1696,6 +1757,15 @@ int dcvc_conv_create(int dtype, int cin, int cout, int kh, int kw, int stride, i
     rc |= upload_f32(h->b, Np, [&](int n) { const int nl = to_log(n); return nl >= 0 ? b[nl] : 0.f; });
     if (rc == 0 && dtype == DCVC_F16 && taps == 1 && epilogue != DCVC_EPI_SHUFFLE2 && Np == Kp && Np == round_up(cout, 64) && t128_width_ok(Np))
         rc |= pack_t128_square_any(Np, h->w_t128, [&](int n, int k) { return (n < cout && k < cin) ? w[(size_t)n * cin + k] : 0.f; });
+    if (rc == 0 && dtype == DCVC_F16 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && Kp % 64 == 0 && Kp <= 256 && Np % 256 == 0 &&
+        (epilogue == DCVC_EPI_BIAS || (epilogue == DCVC_EPI_SHUFFLE2 && h->cs_p % 256 == 0))) {
+        auto WC = [&](int n, int t, int ci) {
+            const int nl = to_log(n);
+            return (nl >= 0 && ci < cin) ? w[((size_t)nl * cin + ci) * taps + t] : 0.f;
+        };
+        rc |= pack_t128_conv3x3(h->w_c128[0], 1, Np, Kp, WC);
+        rc |= pack_t128_conv3x3(h->w_c128[1], 2, Np, Kp, WC);
+    }
     if (rc) return rc < 0 ? rc : dcvc::E_MEM;
     *out = h.release();
     return 0;

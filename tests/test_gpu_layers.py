@@ -259,6 +259,11 @@ CONV_CASES = [
     (514, 256, 1, 1, 0, "bias", 5, 7),
     (320, 192, 1, 1, 0, "bias", 7, 7),
     (384, 256, 1, 1, 0, "wsilu", 6, 5),
+    # 3x3 s1 p1 with 256-channel output slices: conv3x3_t128_kernel in fp16 (several tiles, ragged edges, K = 64 ... 256)
+    (128, 1024, 3, 1, 1, "shuffle", 19, 35),
+    (192, 512, 3, 1, 1, "bias", 11, 17),
+    (64, 256, 3, 1, 1, "bias", 9, 20),
+    (256, 256, 3, 1, 1, "bias", 17, 16),
 ]
 EPI = {"bias": 0, "quant": 1, "shuffle": 2, "wsilu": 3}
 
@@ -295,6 +300,35 @@ def test_conv(case, dtype):
     assert got.shape[:2] == ref.shape[:2]
     assert not np.any(got[:, :, c_log:]), "pad channels must stay zero"
     compare(got[:, :, :c_log], ref, dtype, f"conv {case}")
+
+
+def _conv3x3_out(cin, cout, epi, H, W):
+    from opendcvc_amd import nn
+    rng = _rng(700 + cin + cout)
+    sd = {"m.weight": (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32),
+          "m.bias": (rng.standard_normal(cout) * 0.1).astype(np.float32)}
+    x = rng.standard_normal((H, W, cin)).astype(np.float32)
+    conv = nn.Conv2d(sd, "m", torch.float16, 1, 1, EPI[epi])
+    out = conv(to_dev(x, conv.cin_p, torch.float16))
+    torch.cuda.synchronize()
+    return out.float().cpu().numpy()
+
+
+def test_conv3x3_t128_equals_conv_kernel_bitwise(tmp_path):
+    """conv3x3_t128_kernel accumulates (tap, k) in conv_kernel's order: identical outputs with DCVC_C128=0 (a separate
+    process: the switch is read once)."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = {}
+    for v in ("1", "0"):
+        path = tmp_path / f"o{v}.npy"
+        code = ("import sys, numpy as np; sys.path[:0] = [%r, %r, %r]; import test_gpu_layers as t; "
+                "np.save(%r, np.concatenate([t._conv3x3_out(128, 1024, 'shuffle', 68, 120).ravel(), "
+                "t._conv3x3_out(192, 256, 'bias', 21, 37).ravel()]))"
+                % (here, os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), str(path)))
+        subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, DCVC_C128=v))
+        outs[v] = np.load(path)
+    assert np.array_equal(outs["1"], outs["0"])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
