@@ -140,7 +140,7 @@ class YUV420FileReader:
 
 def _to_device(planes, device):
     import torch
-    return [torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in planes]
+    return [torch.from_numpy(np.array(p, copy=True)).to(device) for p in planes]     # (the planes may be read-only views of the file buffer)
 
 
 # ---------------------------------------------------------------------------------- one rate point

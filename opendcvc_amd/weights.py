@@ -31,7 +31,11 @@ _HEAD_BIAS = {
 _GAIN = {"encoder.down": 0.2, "enc.enc_2.6": 0.2, "decoder.conv2": 0.35, "feature_adaptor_p": 0.7}
 
 
-def make_state_dict(model, seed=1234):
+def make_state_dict(model, seed=1234, q_ramp=False):
+    """q_ramp: the per-qp quantisation tables move with qp over a 16:1 range - a per-channel factor in [0.7, 1.4] times
+    2^(+-(qp - 31.5) / 15.75), rising for the encoder-side tables, falling for the decoder-side ones (names with "dec" /
+    "recon"), like a trained model's - instead of independent draws from [0.5, 1.5] per (qp, channel): rate points that
+    really move with qp (tests/golden/sweep_ramp.json).  The other tensors are drawn exactly as without it."""
     spec = arch.spec_for(model)
     rng = np.random.Generator(np.random.PCG64(seed))
     heads = _HEAD_BIAS[model]
@@ -52,7 +56,12 @@ def make_state_dict(model, seed=1234):
         elif kind == "b":
             v = rng.standard_normal(shape) * 0.05
         elif kind == "q":
-            v = rng.uniform(0.5, 1.5, shape)
+            v = rng.uniform(0.5, 1.5, shape)          # (drawn either way: the stream of random numbers stays the same)
+            if q_ramp:
+                per_channel = 0.7 + 0.7 * (v[:1] - 0.5)
+                qp = np.arange(shape[0], dtype=np.float64).reshape((-1,) + (1,) * (len(shape) - 1))
+                sign = -1.0 if ("dec" in name or "recon" in name) else 1.0
+                v = per_channel * 2.0 ** (sign * (qp - 31.5) / 15.75)
         elif kind == "bitparm":
             v = rng.standard_normal(shape) * 0.5
         else:

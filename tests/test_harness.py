@@ -76,14 +76,14 @@ def test_one_rate_point_end_to_end(tmp_path):
     assert 0 < log["ave_all_frame_psnr"] < 60 and log["ave_all_frame_msssim"] == 0      # (untrained synthetic weights: single-digit dB)
 
 
-def _nets(dtype):
+def _nets(dtype, q_ramp=False):
     import torch
     from opendcvc_amd import weights
     from opendcvc_amd.models import DMC, DMCI
     nets = []
     for cls, name in ((DMCI, "dmci"), (DMC, "dmc")):
         m = cls()
-        m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.make_state_dict(name, 1234).items()})
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.make_state_dict(name, 1234, q_ramp=q_ramp).items()})
         m.to("cuda").eval()
         m.update(0.12)
         nets.append(m.half() if dtype == "fp16" else m)
@@ -92,25 +92,31 @@ def _nets(dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["fp32", "fp16"])
-def test_qp_sweep_matches_reference_rd_points(tmp_path, golden_dir, mode):
+@pytest.mark.parametrize("gold_name", ["sweep.json", "sweep_ramp.json"])
+def test_qp_sweep_matches_reference_rd_points(tmp_path, golden_dir, mode, gold_name):
     """BASELINE.json configs[2]: the qp sweep {0, 21, 42, 63} of one YUV 4:2:0 file through harness.run_sweep against
     the log the REFERENCE's own run_one_point_with_stream wrote for the same file and weights
     (tests/golden/make_golden_sweep.py -> sweep.json): same keys in the same order; fp32: every frame's bits within
     one byte (= bpp within 1e-4 at these stream sizes is byte-exactness) and PSNR within 1e-4 dB; fp16: bpp within
-    2 %, PSNR within 0.05 dB - against the reference's fp32 run and against its own fp16 (CPU) run."""
+    2 %, PSNR within 0.05 dB - against the reference's fp32 run and against its own fp16 (CPU) run.
+    sweep_ramp.json: the same with qp tables that span a 16:1 range (weights.make_state_dict(q_ramp=True)): the reference's
+    rate goes 0.38 -> 0.55 -> 1.48 bpp over qp 0 / 32 / 63 (the independent draws of sweep.json give a flat 0.45)."""
     import hashlib
     import sys
     sys.path.insert(0, golden_dir)
     from make_golden_sweep import write_yuv420
-    gold = json.load(open(os.path.join(golden_dir, "sweep.json")))
+    gold = json.load(open(os.path.join(golden_dir, gold_name)))
     cfg = gold["config"]
+    q_ramp = bool(cfg.get("q_ramp", False))
     W, H, N = cfg["width"], cfg["height"], cfg["frames"]
     src = str(tmp_path / "seq.yuv")
     write_yuv420(src, W, H, N, cfg["src_seed"])
     assert hashlib.sha256(open(src, "rb").read()).hexdigest() == gold["src_sha256"]
-    logs = harness.run_sweep(lambda: _nets(mode), src, W, H, N, qp_i=cfg["qps"], bin_prefix=str(tmp_path / "o"),
+    logs = harness.run_sweep(lambda: _nets(mode, q_ramp), src, W, H, N, qp_i=cfg["qps"], bin_prefix=str(tmp_path / "o"),
                              intra_period=cfg["intra_period"], reset_interval=cfg["reset_interval"], verbose_json=True)
-    assert list(logs.keys()) == cfg["qps"] == harness.sweep_qps(4)
+    assert list(logs.keys()) == cfg["qps"]
+    if not q_ramp:
+        assert cfg["qps"] == harness.sweep_qps(4)
     exact = 0
     for qp in cfg["qps"]:
         got = logs[qp]
@@ -144,7 +150,7 @@ def test_qp_sweep_matches_reference_rd_points(tmp_path, golden_dir, mode):
     out = os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out")
     os.makedirs(out, exist_ok=True)
     json.dump(dict(points={str(k): v for k, v in logs.items()}, containers_byte_identical=exact),
-              open(os.path.join(out, f"sweep_{mode}.json"), "w"), indent=1)
+              open(os.path.join(out, f"sweep{'_ramp' if q_ramp else ''}_{mode}.json"), "w"), indent=1)
 
 
 @pytest.mark.gpu
