@@ -1,6 +1,9 @@
 // dcb_t128.hpp - DepthConvBlock tail for large maps, fp16: 128-pixel tiles, one 8-wave workgroup per CU (two waves per
 // SIMD, 256 registers each), v_mfma_f32_32x32x16_f16, the FFN gate software-pipelined into each wave's own MFMA stream.
 // Included by dcvc_nn.hip inside its anonymous namespace, after TailParams (same parameter block, plus `wt`).
+// Further down, in the same form (waves = channel quarter x pixel half, weights as per-quarter fragment streams through a
+// register ring): dcb_head128_kernel (the block's adaptor + first conv on large maps) and conv3x3_t128_kernel (3x3 stride-1
+// convs as pixel tile x output-channel slice).
 //
 // Why this form (measurements: tools/coissue_mb.hip, tools/mb/valu_rate_mb.hip):
 //   * Two waves of one SIMD do NOT overlap matrix and vector work (their times add), but ONE wave's instruction stream

@@ -1203,7 +1203,7 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     constexpr bool kHeadInKernel = sizeof(T) == 2 && MT == 2 && (NTW <= 4 || NTW == 6);   // (6: the 8-wave tail of C=384)
     const bool head_in = kHeadInKernel && !ch.head_done && !ch.separate_head && !h->adapt && src.c1 == 0;
     if (ev) DCVC_HIP(hipEventRecord(ev[0], st));
-    // large maps, widths 256 / 320 / 384: the 128-pixel head (sources of 64-channel multiples, at most 256 channels each)
+    // large maps, widths 256 / 320 / 384: the 128-pixel head (sources of 64-channel multiples)
     bool head128 = false;
     if constexpr (sizeof(T) == 2 && MT == 4 && (NTW == 4 || NTW == 5 || NTW == 6)) {
         head128 = t128_enabled() && h128_enabled() && !ch.head_done && !head_in && h->w1_t128.p != nullptr &&
