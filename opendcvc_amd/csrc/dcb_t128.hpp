@@ -47,9 +47,34 @@ constexpr int LDS_S = DW_SLAB;                // halo slab rows unpadded: 8 lane
                                               // pixel's - with 128-byte rows the four 64-byte pieces of a ds_read_b128 lane group
                                               // fall on the four bank quarters (a 144-byte stride made them collide two-way)
 
-template <int C>
+constexpr int PADF = 24;                      // dummy fragments behind every per-quarter stream: a ring (<= PADF deep) refills
+                                              // without a clamp, and the two tile geometries share the packed streams
+
+// Tile geometry of the tail kernel.  G128: the large-map form described above.  G32 (maps below 12 000 pixels, where 128-pixel
+// tiles would leave most CUs idle): 32-pixel tiles, four waves = the four channel quarters (one per SIMD, up to two workgroups
+// per CU), all 32 pixels in one MFMA column block.  A workgroup then streams the block's whole weights for 32 pixels, so the
+// kernel lives on the stream: the ring is 24 fragments deep (tools/mb/stream_mb.hip: 255 workgroups read 2 MB each at
+// 55 B/clk/CU with 64 KiB in flight per CU, 81 with 128 KiB; the 16x16x32 kernels this replaces got 20).
+struct G128 {
+    static constexpr int TW = t128::TW, TH = t128::TH, NW = t128::NW, D = 8, DW_SLAB = t128::DW_SLAB, WPS = 2;
+};
+struct G32 {
+    static constexpr int TW = 8, TH = 4, NW = 4, D = 24, DW_SLAB = 128, WPS = 1;
+};
+template <class G>
+struct Geo : G {
+    static constexpr int M = G::TW * G::TH, NTHR = G::NW * 64;
+    static constexpr int PTW = (M / 32) / (G::NW / 4);         // pixel tiles of 32 per wave
+    static constexpr int HALO = (G::TH + 2) * (G::TW + 2);
+    static constexpr int LDS_S = G::DW_SLAB;                   // halo slab rows unpadded (see LDS_S above)
+    static_assert(M % 32 == 0 && PTW >= 1 && G::NW % 4 == 0, "tile geometry");
+};
+
+template <int C, class G = G128>
 struct Cfg {
+    using GE = Geo<G>;
     static_assert(C % 64 == 0, "DepthConvBlock widths are padded to 64");
+    static_assert(C % G::DW_SLAB == 0, "whole depthwise slabs");
     static constexpr int NT = C / 32;                 // output channel tiles; tile cq + 4 i belongs to channel quarter cq
     static constexpr int NTW = (NT + 3) / 4;          // ... per channel quarter (C = 320: 3, 3, 2, 2 - the two missing
     static constexpr bool RAG = NT % 4 != 0;          // tiles run on zero weights and are dropped)
@@ -58,16 +83,18 @@ struct Cfg {
     static constexpr int F4 = 4 * NTW;                // fragments of one W4 chunk pass
     // ring depth: fragments requested ahead of their use.  Every phase's ring slots are static: phases start at a
     // compile-time offset into the ring
-    static constexpr int D = 8;
+    static constexpr int D = G::D;
+    static_assert(D <= PADF, "stream padding");
     static constexpr int LDX = C + PAD;
     static constexpr int FRAGS = KS * NTW + NCH * KS + NCH * F4;   // fragments per channel quarter
-    static constexpr int STREAM = FRAGS + D;          // + D dummies: the ring refill never needs a clamp
-    static constexpr size_t v_elems = (size_t)2 * M * LDV > (size_t)2 * HALO * LDS_S ? (size_t)2 * M * LDV : (size_t)2 * HALO * LDS_S;
+    static constexpr int STREAM = FRAGS + PADF;       // + dummies: the ring refill never needs a clamp
+    static constexpr size_t v_elems = (size_t)2 * GE::M * LDV > (size_t)2 * GE::HALO * GE::LDS_S ? (size_t)2 * GE::M * LDV
+                                                                                                  : (size_t)2 * GE::HALO * GE::LDS_S;
     // small tables staged in LDS once (every thread needs them, 8 - 64 threads each the same 16 bytes: through the L1 that
     // is 90 KB of requests per slab for the depthwise taps alone): depthwise taps [9][C] halfs, depthwise bias [C] floats,
     // FFN bias [4 C] floats
     static constexpr size_t TAB_BYTES = (size_t)9 * C * 2 + (size_t)C * 4 + (size_t)4 * C * 4;
-    static constexpr size_t LDS = ((size_t)M * LDX + v_elems) * sizeof(half_t) + TAB_BYTES;
+    static constexpr size_t LDS = ((size_t)GE::M * LDX + v_elems) * sizeof(half_t) + TAB_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(NCH % 2 == 0 && NCH >= 4, "the chunk loop is unrolled by two");
     static_assert((2 * C) % VC == 0, "whole FFN chunks");
@@ -90,11 +117,15 @@ __device__ __forceinline__ floatx16 mfma32(const half8& a, const half8& b, const
 // C/D layout of the 32x32 tile: lane (pl = lane & 31 -> pixel, hh = lane >> 5), register reg -> row (channel)
 // (reg & 3) + 8 (reg >> 2) + 4 hh: four quads of 4 consecutive channels at 8 g + 4 hh, g = 0..3.
 
-template <int C>
-__global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
+template <int C, class G = G128>
+__global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailParams p)
 {
     using TR = Traits<half_t>;
-    using CF = Cfg<C>;
+    using CF = Cfg<C, G>;
+    using GE = Geo<G>;
+    // (the geometry's values under the names the code below was written with: they shadow the namespace-level G128 constants)
+    constexpr int TW = GE::TW, TH = GE::TH, M = GE::M, NTHR = GE::NTHR, PTW = GE::PTW, HALO = GE::HALO, DW_SLAB = GE::DW_SLAB,
+                  LDS_S = GE::LDS_S;
     constexpr int NTW = CF::NTW, KS = CF::KS, NCH = CF::NCH, D = CF::D, LDX = CF::LDX, V = 8, GC = C / V;
     extern __shared__ __attribute__((aligned(32))) char smem[];
     half_t* bufX = reinterpret_cast<half_t*>(smem);
@@ -180,13 +211,13 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
 #pragma unroll
     for (int sl = 1; sl < nslab; ++sl) fetch(sl);
     constexpr int NID = M * GC / NTHR;
-    // identity / output pass: item k of this thread -> pixel m = tid / 8 + 64 (k / G8), channel group tid % 8 + 8 (k % G8)
+    // identity / output pass: item k of this thread -> pixel m = tid / 8 + (NTHR / 8) (k / G8), channel group tid % 8 + 8 (k % G8)
     // (eight threads cover 128 contiguous bytes of a pixel; no division per item, nothing to keep in registers)
-    constexpr int G8 = C / 64;
-    static_assert(NID == 2 * G8 && NTHR / 8 == M / 2, "identity pass mapping");
+    constexpr int G8 = C / 64, RPP = NTHR / 8;          // rows (pixels) per pass of the workgroup
+    static_assert(M % RPP == 0 && NID == (M / RPP) * G8, "identity pass mapping");
     auto idmap = [&](int k, int& m, int& c) __attribute__((always_inline)) {
         c = ((tid & 7) + 8 * (k % G8)) * V;
-        m = (tid >> 3) + (M / 2) * (k / G8);
+        m = (tid >> 3) + RPP * (k / G8);
     };
     Vec16 idv[NID];
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -509,8 +540,8 @@ __global__ __launch_bounds__(NTHR, 2) void dcb_tail128_kernel(TailParams p)
     // the fused next-block head / 1x1 conv (below): its first weight fragments are requested now, underneath the r epilogue
     const bool fused_next = p.nwt != nullptr;
     const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(fused_next ? p.nwt : p.wt)) + (size_t)cqw * (KS * NTW + D) * 1024, 0,
-        (KS * NTW + D) * 1024, 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(fused_next ? p.nwt : p.wt)) + (size_t)cqw * (KS * NTW + PADF) * 1024, 0,
+        (KS * NTW + PADF) * 1024, 0x00020000);
     int noff = 0;
     auto nload = [&]() __attribute__((always_inline)) {
         typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
@@ -682,7 +713,7 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_head128_kernel(HeadParams p)
     // fragment streams: offsets in a vector register, so a read past the stream's end is range-checked to zero
     auto make_stream = [&](const void* base, int frags) __attribute__((always_inline)) {
         return __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(reinterpret_cast<const char*>(base)) + (size_t)cqw * (frags + CF::D) * 1024, 0, (frags + CF::D) * 1024,
+            const_cast<char*>(reinterpret_cast<const char*>(base)) + (size_t)cqw * (frags + PADF) * 1024, 0, (frags + PADF) * 1024,
             0x00020000);
     };
     floatx16 acc[NTW][PTW];

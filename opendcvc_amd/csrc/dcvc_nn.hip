@@ -1047,7 +1047,7 @@ template <int C>
 int pack_t128_square(DevBuf& dst, const std::function<float(int, int)>& W)
 {
     using CF = t128::Cfg<C>;
-    constexpr int LEN = CF::KS * CF::NTW + CF::D;
+    constexpr int LEN = CF::KS * CF::NTW + t128::PADF;
     std::vector<half_t> buf((size_t)4 * LEN * 512, (half_t)0.f);
     for (int cq = 0; cq < 4; ++cq) {
         size_t f = 0;
@@ -1066,7 +1066,7 @@ template <int C>
 int pack_t128_rect(DevBuf& dst, int Kp, const std::function<float(int, int)>& W)
 {
     using CF = t128::Cfg<C>;
-    const int ks = Kp / 16, LEN = ks * CF::NTW + CF::D;
+    const int ks = Kp / 16, LEN = ks * CF::NTW + t128::PADF;
     std::vector<half_t> buf((size_t)4 * LEN * 512, (half_t)0.f);
     for (int cq = 0; cq < 4; ++cq) {
         size_t f = 0;
@@ -1113,18 +1113,24 @@ static bool t128_enabled()
     return on;
 }
 
+static bool t32_enabled()    // DCVC_T32=0: small-map tails (widths 256 / 384) by dcb_tail_kernel (A/B measurements, bit-identity checks)
+{
+    static const bool on = !(getenv("DCVC_T32") && atoi(getenv("DCVC_T32")) == 0);
+    return on;
+}
+
 static bool h128_enabled()   // DCVC_H128=0: large-map heads by dcb_head_kernel (A/B measurements, bit-identity checks)
 {
     static const bool on = !(getenv("DCVC_H128") && atoi(getenv("DCVC_H128")) == 0);
     return on;
 }
 
-template <int C>
+template <int C, class G = t128::G128>
 int launch_tail128(const TailParams& tp, int H, int W, hipStream_t st)
 {
-    const int grid = ((H + t128::TH - 1) / t128::TH) * ((W + t128::TW - 1) / t128::TW);
-    const size_t lds = t128::Cfg<C>::LDS;
-    int rc = set_lds(t128::dcb_tail128_kernel<C>, lds);
+    const int grid = ((H + G::TH - 1) / G::TH) * ((W + G::TW - 1) / G::TW);
+    const size_t lds = t128::Cfg<C, G>::LDS;
+    int rc = set_lds(t128::dcb_tail128_kernel<C, G>, lds);
     if (rc) return rc;
 #ifdef DCVC_DIAG      // developer build only (make diag): in-kernel phase stamps, median over the workgroups
     static const bool want_stamps = getenv("DCVC_STAMPS") != nullptr;
@@ -1132,7 +1138,7 @@ int launch_tail128(const TailParams& tp, int H, int W, hipStream_t st)
         TailParams q = tp;
         q.ablate = getenv("DCVC_ABLATE") ? atoi(getenv("DCVC_ABLATE")) : 0;     // timing experiments (wrong results)
         DCVC_HIP(hipMalloc(&q.stamps, (size_t)grid * 16 * sizeof(unsigned long long)));
-        hipLaunchKernelGGL((t128::dcb_tail128_kernel<C>), dim3(grid), dim3(t128::NTHR), lds, st, q);
+        hipLaunchKernelGGL((t128::dcb_tail128_kernel<C, G>), dim3(grid), dim3(t128::Geo<G>::NTHR), lds, st, q);
         DCVC_HIP(hipStreamSynchronize(st));
         std::vector<unsigned long long> hs((size_t)grid * 16);
         DCVC_HIP(hipMemcpy(hs.data(), q.stamps, hs.size() * 8, hipMemcpyDeviceToHost));
@@ -1140,7 +1146,7 @@ int launch_tail128(const TailParams& tp, int H, int W, hipStream_t st)
         static int printed = 0;
         if (printed++ % 16 == 15) {
             const char* names[14] = {"loads+dw", "gemm2", "o_pass", "u0", "ffn", "r+store", "", "", "dw:issue+stage0", "barrier0", "slab0", "slab1", "slab2", "slab3"};
-            fprintf(stderr, "[t128 stamps C=%d grid=%d]", C, grid);
+            fprintf(stderr, "[t128 stamps C=%d tile=%d grid=%d]", C, t128::Geo<G>::M, grid);
             for (int k = 0; k < 14; ++k) {
                 if (k == 6 || k == 7) continue;
                 std::vector<unsigned long long> v(grid);
@@ -1156,7 +1162,7 @@ int launch_tail128(const TailParams& tp, int H, int W, hipStream_t st)
         return 0;
     }
 #endif
-    hipLaunchKernelGGL((t128::dcb_tail128_kernel<C>), dim3(grid), dim3(t128::NTHR), lds, st, tp);
+    hipLaunchKernelGGL((t128::dcb_tail128_kernel<C, G>), dim3(grid), dim3(t128::Geo<G>::NTHR), lds, st, tp);
     return 0;
 }
 
@@ -1201,7 +1207,14 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     // Small maps (32-pixel tiles, 4-wave tails), block without adaptor, one source: no head launch - the tail computes
     // `a` on its tile + halo itself (dcb_tail_kernel<..., HEADIN>)
     constexpr bool kHeadInKernel = sizeof(T) == 2 && MT == 2 && (NTW <= 4 || NTW == 6);   // (6: the 8-wave tail of C=384)
-    const bool head_in = kHeadInKernel && !ch.head_done && !ch.separate_head && !h->adapt && src.c1 == 0;
+    // Small maps, widths 256 / 384 (fp16): the 32-pixel form of dcb_tail128_kernel (dcb_t128.hpp, geometry G32) - it wants `a`
+    // from a head launch or the previous block's tail, like the large-map form
+    bool t32 = false;
+    if constexpr (sizeof(T) == 2 && MT == 2 && (NTW == 4 || NTW == 6)) {
+        const bool fuse_ok = ch.next ? ch.next->w1_t128.p != nullptr : ch.conv ? ch.conv->w_t128.p != nullptr : true;
+        t32 = h->wt128.p != nullptr && t128_enabled() && t32_enabled() && fuse_ok;
+    }
+    const bool head_in = kHeadInKernel && !ch.head_done && !ch.separate_head && !h->adapt && src.c1 == 0 && !t32;
     if (ev) DCVC_HIP(hipEventRecord(ev[0], st));
     // large maps, widths 256 / 320 / 384: the 128-pixel head (sources of 64-channel multiples)
     bool head128 = false;
@@ -1309,6 +1322,17 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         tp.stamps = d_stamps;
     }
 #endif
+    if constexpr (sizeof(T) == 2 && MT == 2 && (NTW == 4 || NTW == 6)) {
+        if (t32) {
+            tp.wt = h->wt128.p;
+            tp.nwt = ch.next ? ch.next->w1_t128.p : ch.conv ? ch.conv->w_t128.p : nullptr;
+            int rc = launch_tail128<NTW * 64, t128::G32>(tp, H, W, st);
+            if (rc) return rc;
+            DCVC_LAUNCH_CHECK();
+            if (ev) DCVC_HIP(hipEventRecord(ev[2], st));
+            return 0;
+        }
+    }
     if constexpr (sizeof(T) == 2 && MT == 4 && (NTW == 4 || NTW == 5 || NTW == 6)) {
         // large maps, widths 256 / 384: 128-pixel tiles, one 4-wave workgroup per CU, gate pipelined into the MFMA stream
         const void* nwt = ch.next ? ch.next->w1_t128.p : ch.conv ? ch.conv->w_t128.p : nullptr;

@@ -199,6 +199,43 @@ def test_chained_blocks_equal_separate_calls(c, hw, dtype):
     assert not blocks[2].can_follow(blocks[1], q)
 
 
+def _small_map_outputs():
+    """fp16 blocks on maps below 12 000 pixels, widths 256 / 368 (-> 384): a 4-block chain behind an adaptor block (fused
+    heads, quant at the end), a shortcut + quant block, a 2-block chain ending in a fused 1x1 conv with quant"""
+    from opendcvc_amd import _lib, nn
+    outs = []
+    for c, (H, W) in ((256, (21, 19)), (368, (12, 27)), (256, (68, 120))):
+        rng = _rng(4000 + c + H)
+        blocks = [nn.DepthConvBlock(make_dcb_weights(rng, "m", 2 * c if i == 0 else c, c, i == 0), "m", torch.float16) for i in range(4)]
+        x0 = to_dev(rng.standard_normal((H, W, 2 * c)).astype(np.float32), blocks[0].cin_p, torch.float16)
+        q = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)).cuda()
+        outs.append(nn.dcb_chain(blocks, x0, quant=q))
+        sc = nn.DepthConvBlock(make_dcb_weights(rng, "m", c, c, False), "m", torch.float16, shortcut=True)
+        x1 = to_dev(rng.standard_normal((H, W, c)).astype(np.float32), sc.cin_p, torch.float16)
+        outs.append(sc(x1, quant=q))
+        csd = {"o.weight": (rng.standard_normal((c, c, 1, 1)) / np.sqrt(c)).astype(np.float32),
+               "o.bias": (rng.standard_normal(c) * 0.1).astype(np.float32)}
+        conv = nn.Conv2d(csd, "o", torch.float16, epilogue=_lib.EPI_BIAS_QUANT)
+        outs.append(nn.dcb_chain(blocks[1:3], x1, then_conv=conv, conv_quant=q))
+    torch.cuda.synchronize()
+    return np.concatenate([o.float().cpu().numpy().ravel() for o in outs])
+
+
+def test_tail32_equals_tail_kernel_bitwise(tmp_path):
+    """The 32-pixel form of dcb_tail128_kernel (small maps, widths 256 / 384) stores and rounds where dcb_tail_kernel does and
+    accumulates in the same k order: identical outputs with DCVC_T32=0 (a separate process: the switch is read once)."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = {}
+    for v in ("1", "0"):
+        path = tmp_path / f"o{v}.npy"
+        code = ("import sys, numpy as np; sys.path[:0] = [%r, %r, %r]; import test_gpu_layers as t; np.save(%r, t._small_map_outputs())"
+                % (here, os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), str(path)))
+        subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, DCVC_T32=v))
+        outs[v] = np.load(path)
+    assert np.isfinite(outs["1"]).all() and np.array_equal(outs["1"], outs["0"])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("quant", [False, True])
 @pytest.mark.parametrize("c,hw", [(256, (21, 19)), (128, (9, 33)), (320, (40, 37)), (320, (101, 123)), (256, (101, 123)), (384, (99, 125))])
