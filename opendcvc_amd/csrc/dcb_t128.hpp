@@ -59,7 +59,7 @@ struct G128 {
     static constexpr int TW = t128::TW, TH = t128::TH, NW = t128::NW, D = 8, DW_SLAB = t128::DW_SLAB, WPS = 2;
 };
 struct G32 {
-    static constexpr int TW = 8, TH = 4, NW = 4, D = 24, DW_SLAB = 128, WPS = 1;
+    static constexpr int TW = 8, TH = 4, NW = 4, D = 24 /* divides the fragments of two FFN steps at every width; 36 at C = 384 measured slower (ring in the accumulator file) */, DW_SLAB = 128, WPS = 1;
 };
 template <class G>
 struct Geo : G {
@@ -70,24 +70,31 @@ struct Geo : G {
     static_assert(M % 32 == 0 && PTW >= 1 && G::NW % 4 == 0, "tile geometry");
 };
 
-template <int C, class G = G128>
-struct Cfg {
-    using GE = Geo<G>;
+// the weight streams of a width (what the host packs): independent of the tile geometry
+template <int C>
+struct Wcfg {
     static_assert(C % 64 == 0, "DepthConvBlock widths are padded to 64");
-    static_assert(C % G::DW_SLAB == 0, "whole depthwise slabs");
     static constexpr int NT = C / 32;                 // output channel tiles; tile cq + 4 i belongs to channel quarter cq
     static constexpr int NTW = (NT + 3) / 4;          // ... per channel quarter (C = 320: 3, 3, 2, 2 - the two missing
     static constexpr bool RAG = NT % 4 != 0;          // tiles run on zero weights and are dropped)
     static constexpr int KS = C / 16;                 // k-steps over C
     static constexpr int NCH = 2 * C / VC;            // FFN chunks
     static constexpr int F4 = 4 * NTW;                // fragments of one W4 chunk pass
+    static constexpr int LDX = C + PAD;
+    static constexpr int FRAGS = KS * NTW + NCH * KS + NCH * F4;   // fragments per channel quarter
+    static constexpr int STREAM = FRAGS + PADF;       // + dummies: the ring refill never needs a clamp
+};
+
+template <int C, class G = G128>
+struct Cfg : Wcfg<C> {
+    using GE = Geo<G>;
+    using WC = Wcfg<C>;
+    using WC::NT; using WC::NTW; using WC::RAG; using WC::KS; using WC::NCH; using WC::F4; using WC::LDX; using WC::FRAGS; using WC::STREAM;
+    static_assert(C % G::DW_SLAB == 0, "whole depthwise slabs");
     // ring depth: fragments requested ahead of their use.  Every phase's ring slots are static: phases start at a
     // compile-time offset into the ring
     static constexpr int D = G::D;
     static_assert(D <= PADF, "stream padding");
-    static constexpr int LDX = C + PAD;
-    static constexpr int FRAGS = KS * NTW + NCH * KS + NCH * F4;   // fragments per channel quarter
-    static constexpr int STREAM = FRAGS + PADF;       // + dummies: the ring refill never needs a clamp
     static constexpr size_t v_elems = (size_t)2 * GE::M * LDV > (size_t)2 * GE::HALO * GE::LDS_S ? (size_t)2 * GE::M * LDV
                                                                                                   : (size_t)2 * GE::HALO * GE::LDS_S;
     // small tables staged in LDS once (every thread needs them, 8 - 64 threads each the same 16 bytes: through the L1 that

@@ -1006,7 +1006,7 @@ template <int C>
 int pack_t128(DevBuf& dst, const std::function<float(int, int)>& W2, const std::function<float(int, int)>& W3,
               const std::function<float(int, int)>& W4)
 {
-    using CF = t128::Cfg<C>;
+    using CF = t128::Wcfg<C>;
     std::vector<half_t> buf((size_t)4 * CF::STREAM * 512, (half_t)0.f);
     for (int wave = 0; wave < 4; ++wave) {
         size_t f = 0;
@@ -1040,13 +1040,13 @@ int pack_t128(DevBuf& dst, const std::function<float(int, int)>& W2, const std::
     return dst.upload(buf.data(), buf.size() * sizeof(half_t));
 }
 
-inline bool t128_width_ok(int c_p) { return c_p == 256 || c_p == 320 || c_p == 384; }
+inline bool t128_width_ok(int c_p) { return c_p == 256 || c_p == 320 || c_p == 384 || c_p == 512; }   // (512: 32-pixel tiles only)
 
 // a C x C matrix (next block's first conv, a fused 1x1 conv) as the per-quarter fragment stream gemm_c reads
 template <int C>
 int pack_t128_square(DevBuf& dst, const std::function<float(int, int)>& W)
 {
-    using CF = t128::Cfg<C>;
+    using CF = t128::Wcfg<C>;
     constexpr int LEN = CF::KS * CF::NTW + t128::PADF;
     std::vector<half_t> buf((size_t)4 * LEN * 512, (half_t)0.f);
     for (int cq = 0; cq < 4; ++cq) {
@@ -1065,7 +1065,7 @@ int pack_t128_square(DevBuf& dst, const std::function<float(int, int)>& W)
 template <int C>
 int pack_t128_rect(DevBuf& dst, int Kp, const std::function<float(int, int)>& W)
 {
-    using CF = t128::Cfg<C>;
+    using CF = t128::Wcfg<C>;
     const int ks = Kp / 16, LEN = ks * CF::NTW + t128::PADF;
     std::vector<half_t> buf((size_t)4 * LEN * 512, (half_t)0.f);
     for (int cq = 0; cq < 4; ++cq) {
@@ -1103,7 +1103,8 @@ inline int pack_t128_conv3x3(DevBuf& dst, int ntw, int Np, int Kp, const std::fu
 
 inline int pack_t128_square_any(int c_p, DevBuf& dst, const std::function<float(int, int)>& W)
 {
-    return c_p == 256 ? pack_t128_square<256>(dst, W) : c_p == 320 ? pack_t128_square<320>(dst, W) : pack_t128_square<384>(dst, W);
+    return c_p == 256 ? pack_t128_square<256>(dst, W) : c_p == 320 ? pack_t128_square<320>(dst, W)
+                      : c_p == 384 ? pack_t128_square<384>(dst, W) : pack_t128_square<512>(dst, W);
 }
 
 // DCVC_T128=0 keeps the 64-pixel tails on large maps (A/B measurements; both forms pass the same layer tests)
@@ -1207,10 +1208,10 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     // Small maps (32-pixel tiles, 4-wave tails), block without adaptor, one source: no head launch - the tail computes
     // `a` on its tile + halo itself (dcb_tail_kernel<..., HEADIN>)
     constexpr bool kHeadInKernel = sizeof(T) == 2 && MT == 2 && (NTW <= 4 || NTW == 6);   // (6: the 8-wave tail of C=384)
-    // Small maps, widths 256 / 384 (fp16): the 32-pixel form of dcb_tail128_kernel (dcb_t128.hpp, geometry G32) - it wants `a`
+    // Small maps, widths 256 / 384 / 512 (fp16): the 32-pixel form of dcb_tail128_kernel (dcb_t128.hpp, geometry G32) - it wants `a`
     // from a head launch or the previous block's tail, like the large-map form
     bool t32 = false;
-    if constexpr (sizeof(T) == 2 && MT == 2 && (NTW == 4 || NTW == 6)) {
+    if constexpr (sizeof(T) == 2 && MT == 2 && (NTW == 4 || NTW == 6 || NTW == 8)) {
         const bool fuse_ok = ch.next ? ch.next->w1_t128.p != nullptr : ch.conv ? ch.conv->w_t128.p != nullptr : true;
         t32 = h->wt128.p != nullptr && t128_enabled() && t32_enabled() && fuse_ok;
     }
@@ -1322,7 +1323,7 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         tp.stamps = d_stamps;
     }
 #endif
-    if constexpr (sizeof(T) == 2 && MT == 2 && (NTW == 4 || NTW == 6)) {
+    if constexpr (sizeof(T) == 2 && MT == 2 && (NTW == 4 || NTW == 6 || NTW == 8)) {
         if (t32) {
             tp.wt = h->wt128.p;
             tp.nwt = ch.next ? ch.next->w1_t128.p : ch.conv ? ch.conv->w_t128.p : nullptr;
@@ -1596,12 +1597,12 @@ int dcvc_dcb_create(int dtype, int cin, int c, int shortcut, const float* adapto
         auto W4 = [&](int n, int k) { return (n < C && k < 2 * C) ? w4[(size_t)n * 2 * C + k] / ka : 0.f; };
         if (h->adapt && Kp % 64 == 0) {
             auto WA = [&](int n, int k) { return (n < C && k < cin) ? adaptor_w[(size_t)n * cin + k] : 0.f; };
-            rc |= Cp == 256 ? pack_t128_rect<256>(h->wa_t128, Kp, WA) : Cp == 320 ? pack_t128_rect<320>(h->wa_t128, Kp, WA)
+            rc |= Cp == 512 ? 0 : Cp == 256 ? pack_t128_rect<256>(h->wa_t128, Kp, WA) : Cp == 320 ? pack_t128_rect<320>(h->wa_t128, Kp, WA)
                                                                                  : pack_t128_rect<384>(h->wa_t128, Kp, WA);
         }
         rc |= pack_t128_square_any(Cp, h->w1_t128, [&](int n, int k) { return (n < C && k < C) ? ka * w1[(size_t)n * C + k] : 0.f; });
-        rc |= Cp == 256 ? pack_t128<256>(h->wt128, W2, W3, W4)
-                        : Cp == 320 ? pack_t128<320>(h->wt128, W2, W3, W4) : pack_t128<384>(h->wt128, W2, W3, W4);
+        rc |= Cp == 256 ? pack_t128<256>(h->wt128, W2, W3, W4) : Cp == 320 ? pack_t128<320>(h->wt128, W2, W3, W4)
+                        : Cp == 384 ? pack_t128<384>(h->wt128, W2, W3, W4) : pack_t128<512>(h->wt128, W2, W3, W4);
     }
     if (rc) return rc < 0 ? rc : dcvc::E_MEM;
     *out = h.release();

@@ -204,7 +204,7 @@ def _small_map_outputs():
     heads, quant at the end), a shortcut + quant block, a 2-block chain ending in a fused 1x1 conv with quant"""
     from opendcvc_amd import _lib, nn
     outs = []
-    for c, (H, W) in ((256, (21, 19)), (368, (12, 27)), (256, (68, 120))):
+    for c, (H, W) in ((256, (21, 19)), (368, (12, 27)), (512, (14, 20)), (256, (68, 120))):
         rng = _rng(4000 + c + H)
         blocks = [nn.DepthConvBlock(make_dcb_weights(rng, "m", 2 * c if i == 0 else c, c, i == 0), "m", torch.float16) for i in range(4)]
         x0 = to_dev(rng.standard_normal((H, W, 2 * c)).astype(np.float32), blocks[0].cin_p, torch.float16)
