@@ -668,6 +668,13 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
                 *reinterpret_cast<Vec16*>(na + ((long)y * p.W + x) * p.nlda + icg) = lds_load_vec<half_t>(bufX, LDX, m, icg);
         }
     }
+#ifdef DCVC_DIAG
+    if (p.stamps && tid == 0) {
+        unsigned long long ts7 = 0;
+        STAMP(ts7);
+        p.stamps[(size_t)blockIdx.x * 16 + 14] = ts7 - ts6;     // fused next-block head / conv
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -678,21 +685,26 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
 // through LDS in chunks of up to 128 channels (the next chunk's loads are in flight during the current chunk's MFMAs), k
 // ascending across chunks and sources: the accumulation order of the one-pass form, so the values equal dcb_head_kernel's
 // bit for bit.  One workgroup per CU (a 1080p map has 255 tiles): 512 registers per lane.
-template <int C>
+// Geometry G32 (maps below 12 000 pixels, the heads in front of the 32-pixel tails): 32-pixel tiles, four waves.
+template <int C, class G = G128>
 struct HeadCfg {
-    using CF = Cfg<C>;
+    using CF = Wcfg<C>;
     static constexpr int DH = 4 * CF::NTW;          // ring depth = the fragments of 4 k-steps (64 input channels)
     static constexpr int KCH = 128;                 // channels per staged chunk
     static constexpr int LDS_S = KCH + PAD;
-    static constexpr size_t LDS = ((size_t)M * LDS_S + (size_t)M * CF::LDX) * sizeof(half_t);
+    static constexpr size_t LDS = ((size_t)Geo<G>::M * LDS_S + (size_t)Geo<G>::M * CF::LDX) * sizeof(half_t);
 };
 
-template <int C, bool ADAPT>
-__global__ __launch_bounds__(NTHR, 1) void dcb_head128_kernel(HeadParams p)
+template <int C, bool ADAPT, class G = G128>
+__global__ __launch_bounds__(Geo<G>::NTHR, 1) void dcb_head128_kernel(HeadParams p)
 {
     using TR = Traits<half_t>;
-    using CF = Cfg<C>;
-    using HC = HeadCfg<C>;
+    using CF = Wcfg<C>;
+    using HC = HeadCfg<C, G>;
+    using GE = Geo<G>;
+    constexpr int TW = GE::TW, TH = GE::TH, M = GE::M, NTHR = GE::NTHR, PTW = GE::PTW;      // (shadow the G128 constants)
+    constexpr int RPP = NTHR / 8, NPASS = M / RPP;          // pixels per staging pass of the workgroup (8 threads per pixel), passes
+    static_assert(M % RPP == 0, "staging passes");
     constexpr int NTW = CF::NTW, KS = CF::KS, LDX = CF::LDX, V = 8, DH = HC::DH, KCH = HC::KCH, LDS_S = HC::LDS_S, G8 = C / 64;
     extern __shared__ __attribute__((aligned(32))) char smem[];
     half_t* bufY = reinterpret_cast<half_t*>(smem);        // x' (the W1 GEMM's operand), then the output tile
@@ -709,11 +721,11 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_head128_kernel(HeadParams p)
     auto tile_of = [&](int i) __attribute__((always_inline)) { return cqw + 4 * i; };
     auto tile_exists = [&](int i) __attribute__((always_inline)) { return !CF::RAG || cqw + 4 * i < CF::NT; };
 
-    // the two pixels this thread stages / stores (rows tid / 8 and tid / 8 + 64 of the tile): index in the picture or -1
-    int pix2[2];
+    // the pixels this thread stages / stores (rows tid / 8 + RPP k of the tile): index in the picture or -1
+    int pix2[NPASS];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int m = (tid >> 3) + (M / 2) * k;
+    for (int k = 0; k < NPASS; ++k) {
+        const int m = (tid >> 3) + RPP * k;
         const int y = ty0 + m / TW, x = tx0 + m % TW;
         pix2[k] = (y < p.H && x < p.W) ? y * p.W + x : -1;
     }
@@ -762,8 +774,8 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_head128_kernel(HeadParams p)
     auto store_tile = [&](void* g, long ldg) __attribute__((always_inline)) {
         half_t* gp = reinterpret_cast<half_t*>(g);
 #pragma unroll
-        for (int k = 0; k < 2 * G8; ++k) {
-            const int m = (tid >> 3) + (M / 2) * (k / G8), c = ((tid & 7) + 8 * (k % G8)) * V;
+        for (int k = 0; k < NPASS * G8; ++k) {
+            const int m = (tid >> 3) + RPP * (k / G8), c = ((tid & 7) + 8 * (k % G8)) * V;
             const int px = pix2[k / G8];
             if (px >= 0) *reinterpret_cast<Vec16*>(gp + (long)px * ldg + c) = *reinterpret_cast<const Vec16*>(bufY + m * LDX + c);
         }
@@ -815,14 +827,14 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_head128_kernel(HeadParams p)
             0x00020000);
         const int n0 = (p.src.c0 + KCH - 1) / KCH, nchunk = n0 + (p.src.c1 + KCH - 1) / KCH;
         // chunk i: KCH channels (the last chunk of a source may hold 64) -> registers; returns its channel count
-        u32x4 pre[4];
+        u32x4 pre[2 * NPASS];
         auto fetch = [&](int i) __attribute__((always_inline)) {
             const bool s1 = i >= n0;
             const int cb = (s1 ? i - n0 : i) * KCH;
             const int left = (s1 ? p.src.c1 : p.src.c0) - cb, cnt = left < KCH ? left : KCH;
             const int ld = (int)(s1 ? p.src.ld1 : p.src.ld0);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 2 * NPASS; ++k) {
                 const int c = ((tid & 7) + 8 * (k & 1)) * V, px = pix2[k >> 1];
                 const int off = (px >= 0 && c < cnt) ? (px * ld + cb + c) * 2 : OOB;
                 pre[k] = s1 ? __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0);
@@ -835,8 +847,8 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_head128_kernel(HeadParams p)
         for (int i = 0; i < nchunk; ++i) {
             if (i > 0) __syncthreads();      // every wave has finished reading the previous chunk
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                *reinterpret_cast<u32x4*>(bufS + ((tid >> 3) + (M / 2) * (k >> 1)) * LDS_S + ((tid & 7) + 8 * (k & 1)) * V) = pre[k];
+            for (int k = 0; k < 2 * NPASS; ++k)
+                *reinterpret_cast<u32x4*>(bufS + ((tid >> 3) + RPP * (k >> 1)) * LDS_S + ((tid & 7) + 8 * (k & 1)) * V) = pre[k];
             const int cur = cnt;
             __syncthreads();
             if (i + 1 < nchunk) cnt = fetch(i + 1);
@@ -852,17 +864,17 @@ __global__ __launch_bounds__(NTHR, 1) void dcb_head128_kernel(HeadParams p)
     } else {
         const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<void*>(p.src.x0), 0, (int)((long)p.H * p.W * p.src.ld0 * 2), 0x00020000);
-        u32x4 xin[2 * G8];
+        u32x4 xin[NPASS * G8];
 #pragma unroll
-        for (int k = 0; k < 2 * G8; ++k) {
+        for (int k = 0; k < NPASS * G8; ++k) {
             const int c = ((tid & 7) + 8 * (k % G8)) * V, px = pix2[k / G8];
             xin[k] = __builtin_amdgcn_raw_buffer_load_b128(rs0, px >= 0 ? (px * (int)p.src.ld0 + c) * 2 : OOB, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < DH; ++k) ring[k] = wnext();
 #pragma unroll
-        for (int k = 0; k < 2 * G8; ++k)
-            *reinterpret_cast<u32x4*>(bufY + ((tid >> 3) + (M / 2) * (k / G8)) * LDX + ((tid & 7) + 8 * (k % G8)) * V) = xin[k];
+        for (int k = 0; k < NPASS * G8; ++k)
+            *reinterpret_cast<u32x4*>(bufY + ((tid >> 3) + RPP * (k / G8)) * LDX + ((tid & 7) + 8 * (k % G8)) * V) = xin[k];
         __syncthreads();
     }
     gemm(bufY, LDX, KS / 4, wnext);

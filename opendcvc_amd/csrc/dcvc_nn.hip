@@ -1146,9 +1146,9 @@ int launch_tail128(const TailParams& tp, int H, int W, hipStream_t st)
         (void)hipFree(q.stamps);
         static int printed = 0;
         if (printed++ % 16 == 15) {
-            const char* names[14] = {"loads+dw", "gemm2", "o_pass", "u0", "ffn", "r+store", "", "", "dw:issue+stage0", "barrier0", "slab0", "slab1", "slab2", "slab3"};
+            const char* names[15] = {"loads+dw", "gemm2", "o_pass", "u0", "ffn", "r+store", "", "", "dw:issue+stage0", "barrier0", "slab0", "slab1", "slab2", "slab3", "fused"};
             fprintf(stderr, "[t128 stamps C=%d tile=%d grid=%d]", C, t128::Geo<G>::M, grid);
-            for (int k = 0; k < 14; ++k) {
+            for (int k = 0; k < 15; ++k) {
                 if (k == 6 || k == 7) continue;
                 std::vector<unsigned long long> v(grid);
                 for (int b = 0; b < grid; ++b) v[b] = hs[(size_t)b * 16 + k];
@@ -1217,26 +1217,33 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     }
     const bool head_in = kHeadInKernel && !ch.head_done && !ch.separate_head && !h->adapt && src.c1 == 0 && !t32;
     if (ev) DCVC_HIP(hipEventRecord(ev[0], st));
-    // large maps, widths 256 / 320 / 384: the 128-pixel head (sources of 64-channel multiples)
+    // widths 256 / 320 / 384 on large maps, 256 / 384 / 512 in front of the 32-pixel tails: the head in the form of dcb_t128.hpp
+    // (sources of 64-channel multiples)
     bool head128 = false;
-    if constexpr (sizeof(T) == 2 && MT == 4 && (NTW == 4 || NTW == 5 || NTW == 6)) {
-        head128 = t128_enabled() && h128_enabled() && !ch.head_done && !head_in && h->w1_t128.p != nullptr &&
-                  (h->adapt ? (h->wa_t128.p != nullptr && src.c0 % 64 == 0 && src.c1 % 64 == 0 && kin == h->cin_p)
-                            : (src.c1 == 0 && src.c0 == NTW * 64));
-        if (head128) {
-            hp.wa128 = h->wa_t128.p;
-            hp.w1128 = h->w1_t128.p;
-            const int g128 = ((H + t128::TH - 1) / t128::TH) * ((W + t128::TW - 1) / t128::TW);
-            const size_t lds = t128::HeadCfg<NTW * 64>::LDS;
-            int rc;
-            if (h->adapt) {
-                rc = set_lds(t128::dcb_head128_kernel<NTW * 64, true>, lds);
-                if (rc) return rc;
-                hipLaunchKernelGGL((t128::dcb_head128_kernel<NTW * 64, true>), dim3(g128), dim3(t128::NTHR), lds, st, hp);
-            } else {
-                rc = set_lds(t128::dcb_head128_kernel<NTW * 64, false>, lds);
-                if (rc) return rc;
-                hipLaunchKernelGGL((t128::dcb_head128_kernel<NTW * 64, false>), dim3(g128), dim3(t128::NTHR), lds, st, hp);
+    {
+        constexpr bool kLarge = sizeof(T) == 2 && MT == 4 && (NTW == 4 || NTW == 5 || NTW == 6);
+        constexpr bool kSmall = sizeof(T) == 2 && MT == 2 && (NTW == 4 || NTW == 6 || NTW == 8);
+        if constexpr (kLarge || kSmall) {
+            using G = typename std::conditional<kLarge, t128::G128, t128::G32>::type;
+            head128 = t128_enabled() && h128_enabled() && (kLarge || t32) && !ch.head_done && !head_in && h->w1_t128.p != nullptr &&
+                      (h->adapt ? (h->wa_t128.p != nullptr && src.c0 % 64 == 0 && src.c1 % 64 == 0 && kin == h->cin_p)
+                                : (src.c1 == 0 && src.c0 == NTW * 64));
+            if (head128) {
+                hp.wa128 = h->wa_t128.p;
+                hp.w1128 = h->w1_t128.p;
+                const int g128 = ((H + G::TH - 1) / G::TH) * ((W + G::TW - 1) / G::TW);
+                const size_t lds = t128::HeadCfg<NTW * 64, G>::LDS;
+                constexpr int NTHR_ = t128::Geo<G>::NTHR;
+                int rc;
+                if (h->adapt) {
+                    rc = set_lds(t128::dcb_head128_kernel<NTW * 64, true, G>, lds);
+                    if (rc) return rc;
+                    hipLaunchKernelGGL((t128::dcb_head128_kernel<NTW * 64, true, G>), dim3(g128), dim3(NTHR_), lds, st, hp);
+                } else {
+                    rc = set_lds(t128::dcb_head128_kernel<NTW * 64, false, G>, lds);
+                    if (rc) return rc;
+                    hipLaunchKernelGGL((t128::dcb_head128_kernel<NTW * 64, false, G>), dim3(g128), dim3(NTHR_), lds, st, hp);
+                }
             }
         }
     }
@@ -1597,8 +1604,8 @@ int dcvc_dcb_create(int dtype, int cin, int c, int shortcut, const float* adapto
         auto W4 = [&](int n, int k) { return (n < C && k < 2 * C) ? w4[(size_t)n * 2 * C + k] / ka : 0.f; };
         if (h->adapt && Kp % 64 == 0) {
             auto WA = [&](int n, int k) { return (n < C && k < cin) ? adaptor_w[(size_t)n * cin + k] : 0.f; };
-            rc |= Cp == 512 ? 0 : Cp == 256 ? pack_t128_rect<256>(h->wa_t128, Kp, WA) : Cp == 320 ? pack_t128_rect<320>(h->wa_t128, Kp, WA)
-                                                                                 : pack_t128_rect<384>(h->wa_t128, Kp, WA);
+            rc |= Cp == 256 ? pack_t128_rect<256>(h->wa_t128, Kp, WA) : Cp == 320 ? pack_t128_rect<320>(h->wa_t128, Kp, WA)
+                            : Cp == 384 ? pack_t128_rect<384>(h->wa_t128, Kp, WA) : pack_t128_rect<512>(h->wa_t128, Kp, WA);
         }
         rc |= pack_t128_square_any(Cp, h->w1_t128, [&](int n, int k) { return (n < C && k < C) ? ka * w1[(size_t)n * C + k] : 0.f; });
         rc |= Cp == 256 ? pack_t128<256>(h->wt128, W2, W3, W4) : Cp == 320 ? pack_t128<320>(h->wt128, W2, W3, W4)

@@ -37,7 +37,61 @@ def run(C, H, W, dtype=torch.float16, iters=30):
     flop = 2.0 * H * W * (7 * C * C + 9 * C)
     print(f"C={C} {H}x{W} {dtype}: head {head.value*1e3:.1f} us  tail {tail.value*1e3:.1f} us  tail {flop/tail.value/1e9:.1f} TFLOP/s  ablate={os.environ.get('DCVC_ABLATE','0')}", flush=True)
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("conv", "adapt")):
+def run_cold(C, H, W, nblk=8, dtype=torch.float16, iters=10):
+    """tails of nblk different blocks in turn (weights of one block no longer sit in L2 when it runs again), `a` precomputed"""
+    rng = np.random.default_rng(0)
+    blks = [L.DepthConvBlock(make_dcb_weights(rng, "m", C, C, False), "m", dtype) for _ in range(nblk)]
+    x = (torch.randn((H, W, blks[0].c_p), device="cuda") * 0.5).to(dtype)
+    out = torch.empty_like(x)
+    lib = _lib.lib()
+    scratch = L.Scratch.get(lib.dcvc_dcb_scratch_bytes(blks[0].h, H, W), x.device)
+    head, tail = ctypes.c_float(), ctypes.c_float()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    tot = 0.0
+    for rep in range(iters + 2):
+        for b in blks:
+            _lib.check(lib.dcvc_dcb_profile(b.h, L._p(x), b.c_p, b.c_p, H, W, L._p(out), b.c_p, L._p(scratch), st, 1, ctypes.byref(head), ctypes.byref(tail)))
+            if rep >= 2:
+                tot += tail.value
+    print(f"C={C} {H}x{W} {nblk} blocks in turn: tail {tot / (iters * nblk) * 1e3:.1f} us per launch", flush=True)
+
+
+def run_chain(C, H, W, n=4, dtype=torch.float16, iters=20):
+    """a run of n blocks as the codec launches it (every tail but the last carries the next block's head)"""
+    rng = np.random.default_rng(0)
+    blks = [L.DepthConvBlock(make_dcb_weights(rng, "m", C, C, False), "m", dtype) for _ in range(n)]
+    x = (torch.randn((H, W, blks[0].c_p), device="cuda") * 0.5).to(dtype)
+    out = torch.empty_like(x)
+    for _ in range(3):
+        L.dcb_chain(blks, x, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        L.dcb_chain(blks, x, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"C={C} {H}x{W} chain of {n}: {e0.elapsed_time(e1) / iters * 1e3:.1f} us (1 head + {n} tails, {n - 1} with a fused head)", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "chain":
+    if len(sys.argv) > 3:
+        run_chain(int(sys.argv[2]), 68, 120, int(sys.argv[3]))
+    else:
+        for C in (256, 384):
+            run_chain(C, 68, 120, 4)
+            run_chain(C, 68, 120, 1)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "cold":
+    for C in (256, 384):
+        run_cold(C, 68, 120)
+        run_cold(C, 68, 120, nblk=1)
+    run_cold(256, 136, 240)
+    run_cold(256, 136, 240, nblk=1)
+
+
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("conv", "adapt", "cold", "chain")):
     shapes = [(256, 136, 240), (256, 68, 120), (384, 68, 120), (128, 17, 30), (320, 136, 240), (384, 136, 240), (512, 68, 120)]
     for C, H, W in shapes if len(sys.argv) < 2 else [tuple(int(v) for v in sys.argv[1:4])]:
         run(C, H, W)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # developer script: launches and kernel time per P-frame pair (the count_launches part of final_measure.sh);
-# second pass with the 128-pixel head and the sliced 3x3 conv switched off (DCVC_H128=0 DCVC_C128=0) on the same box
+# second pass with the 32-pixel ring tails switched off (DCVC_T32=0) on the same box
 set -e
 R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -14,5 +14,5 @@ one() {
   head -2 $1
 }
 one $O/${R}_launches_per_pair.txt
-export DCVC_H128=0 DCVC_C128=0
-one $O/${R}_launches_per_pair_h128_c128_off.txt
+export DCVC_T32=0
+one $O/${R}_launches_per_pair_t32_off.txt

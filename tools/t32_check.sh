@@ -8,3 +8,5 @@ for v in 1 0 1; do
   for C in 256 384 512; do DCVC_T32=$v python tools/kbench.py $C 68 120 2>&1 | grep -v amdgpu.ids | sed "s/^/T32=$v /"; done
 done | tee gpurun_out/t32_kbench.log
 DCVC_AMD_DIAG=1 DCVC_STAMPS=1 python tools/kbench.py 384 68 120 2>&1 | grep stamps | tail -1 | tee -a gpurun_out/t32_kbench.log
+for v in 1 0; do DCVC_T32=$v python tools/kbench.py chain 2>&1 | grep -v amdgpu.ids | sed "s/^/T32=$v /"; done | tee -a gpurun_out/t32_kbench.log
+for v in 1 0; do DCVC_T32=$v python tools/kbench.py adapt 2>&1 | grep "68x120" | sed "s/^/T32=$v /"; done | tee -a gpurun_out/t32_kbench.log
