@@ -72,6 +72,41 @@ def run_chain(C, H, W, n=4, dtype=torch.float16, iters=20):
     e1.record()
     torch.cuda.synchronize()
     print(f"C={C} {H}x{W} chain of {n}: {e0.elapsed_time(e1) / iters * 1e3:.1f} us (1 head + {n} tails, {n - 1} with a fused head)", flush=True)
+    if os.environ.get("KBENCH_GRAPH"):      # the same launches replayed from a captured HIP graph
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(g, stream=side):
+            L.dcb_chain(blks, x, out=out)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            g.replay()
+        e0.record()
+        for _ in range(iters):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"   ... replayed from a HIP graph: {e0.elapsed_time(e1) / iters * 1e3:.1f} us", flush=True)
+
+
+def run_mix(iters=40):
+    """small-map chains between large-map ones (the GPU's clocks then sit where they sit inside a frame, not where a loop of
+    light kernels lets them climb); read the per-kernel durations from a kernel trace"""
+    rng = np.random.default_rng(0)
+    big = [L.DepthConvBlock(make_dcb_weights(rng, "m", 256, 256, False), "m", torch.float16) for _ in range(4)]
+    small = [L.DepthConvBlock(make_dcb_weights(rng, "m", 384, 384, False), "m", torch.float16) for _ in range(4)]
+    xb = (torch.randn((136, 240, 256), device="cuda") * 0.5).half()
+    xs = (torch.randn((68, 120, 384), device="cuda") * 0.5).half()
+    ob, os_ = torch.empty_like(xb), torch.empty_like(xs)
+    for _ in range(iters):
+        L.dcb_chain(big, xb, out=ob)
+        L.dcb_chain(big, xb, out=ob)
+        L.dcb_chain(small, xs, out=os_)
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "mix":
+    run_mix()
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "chain":
@@ -91,7 +126,7 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "cold":
     run_cold(256, 136, 240, nblk=1)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("conv", "adapt", "cold", "chain")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("conv", "adapt", "cold", "chain", "mix")):
     shapes = [(256, 136, 240), (256, 68, 120), (384, 68, 120), (128, 17, 30), (320, 136, 240), (384, 136, 240), (512, 68, 120)]
     for C, H, W in shapes if len(sys.argv) < 2 else [tuple(int(v) for v in sys.argv[1:4])]:
         run(C, H, W)

@@ -13,7 +13,7 @@ sel = [(r['Kernel_Name'], (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) 
 # last 120 launches: kernel short name + duration + gap to previous
 out = []
 prev_end = None
-for r in rows[-140:]:
+for r in rows:
     n = r['Kernel_Name']
     short = ('T32<' + n.split('kernel<')[1][:3] + '>') if 'tail128' in n and 'G32' in n else ('T128<' + n.split('kernel<')[1][:3] + '>') if 'tail128' in n else n.split('(')[0][-28:]
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
