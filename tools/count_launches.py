@@ -28,7 +28,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "--diff":
     print(f"own kernels per P-frame pair: {sum(d.values()):.1f}; torch / runtime kernels (copies, casts): {sum(do.values()):.1f}")
     us = lambda k: (TIMES.get((sys.argv[3], k), 0.0) - TIMES.get((sys.argv[2], k), 0.0)) / n / 1e3
     tot = sum(us(k) for k in list(d) + list(do))
+    is_copy = lambda k: "rocclr" in k
+    is_torch = lambda k: k.startswith("void at::") or "at::native" in k
+    own = sum(us(k) for k in list(d) + list(do) if not is_copy(k) and not is_torch(k))
     print(f"kernel time per P-frame pair (encoder then decoder, one stream, nothing else on the GPU): {tot:.0f} us")
+    print(f"  of which this library's kernels {own:.0f} us, runtime copy commands {sum(us(k) for k in do if is_copy(k)):.0f} us "
+          f"(a difference of two processes: when one of them runs its copies at ~100 us each - seen in about half of the "
+          f"processes, never in bench.py - this term is off, the kernels' is not), torch kernels {sum(us(k) for k in do if is_torch(k)):.0f} us")
     for k, v in sorted(d.items(), key=lambda kv: -us(kv[0])):
         if v:
             print(f"  {v:5.1f} x {us(k) / v:7.1f} us = {us(k):7.1f} us ({100 * us(k) / tot:4.1f} %)  {k[:90]}")
