@@ -76,6 +76,10 @@ DCB_CASES = [
     (512, 512, True, False, False, 6, 10, 256),
     (512, 512, False, False, False, 5, 9, None),
     (256, 128, True, False, False, 4, 4, None),
+    # degenerate maps through the 32-pixel ring tails (one ragged tile; a strip of tiles one row high)
+    (256, 256, False, True, True, 1, 1, None),
+    (384, 384, False, False, False, 3, 50, None),
+    (448, 256, True, False, False, 2, 9, 192),
 ]
 
 
