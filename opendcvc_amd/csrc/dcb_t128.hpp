@@ -1038,4 +1038,143 @@ __global__ __launch_bounds__(NTHR, NTW == 1 ? 4 : 2) void conv3x3_t128_kernel(Co
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Stride-2 convolutions (2x2 without padding, 3x3 with padding 1; one source) as an implicit GEMM on 32 output pixels
+// (8 x 4) x 128 NTW output channels: four waves = the channel quarters, 32x32x16 MFMAs, the weights as one fragment stream per
+// quarter in (tap, k-step, tile) order through a ring of 8 NTW fragments.  conv_kernel re-stages the input once per tap for a
+// stride-2 conv (its one-pass form collides in the LDS banks: rows two pixels apart); here the input tile is staged once with
+// the even and the odd input columns in separate planes, so the 32 pixels of a tap read consecutive rows.  An optional
+// per-input-channel factor is applied while staging (x * in_q[c], rounded to fp16: conv_kernel's scale_vec).  Accumulation
+// order = conv_kernel's (tap major, k ascending): the same values bit for bit.
+struct ConvS2Params {
+    const void* x;
+    long ldx;
+    int H, W, Ho, Wo, kin, k, pad;   // k = 2 or 3
+    const void* wt;                   // [quarter][k k kin / 16 * NTW + D] fragments
+    const float* b;
+    const float* in_q;
+    int in_qn;
+    void* out;
+    long ldo;
+};
+
+constexpr int S2_TW = 8, S2_TH = 4;
+inline size_t conv_s2_lds(int kin, int k, int ntw)
+{
+    const int ih = 2 * S2_TH + k - 2, iwh = S2_TW + 1;
+    const size_t in = (size_t)ih * 2 * iwh * (kin + PAD), out = (size_t)32 * (128 * ntw + PAD);
+    return (in > out ? in : out) * sizeof(half_t);
+}
+
+template <int NTW>
+__global__ __launch_bounds__(256, 1) void conv_s2_t32_kernel(ConvS2Params p)
+{
+    constexpr int N = 128 * NTW, DH = 8 * NTW, V = 8, LDO = N + PAD, TW_ = S2_TW, TH_ = S2_TH, NTHR_ = 256, IWH = S2_TW + 1, G8 = N / 64;
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    const int lds_s = p.kin + PAD;
+    half_t* bufS = reinterpret_cast<half_t*>(smem);          // input tile: [row][column parity][column / 2][kin + PAD]
+    half_t* bufO = bufS;                                      // ... then the output tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int cqw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, hh = lane >> 5;
+    const int tiles_x = (p.Wo + TW_ - 1) / TW_;
+    const int ty0 = (blockIdx.x / tiles_x) * TH_, tx0 = (blockIdx.x % tiles_x) * TW_;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int OOB = 0x7FFFFFF0;
+    const int taps = p.k * p.k, ksteps = p.kin / 16, frags = taps * ksteps * NTW;
+    const int IH = 2 * TH_ + p.k - 2, IW = 2 * TW_ + p.k - 2;
+
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.wt)) + (size_t)cqw * (frags + DH) * 1024, 0, (frags + DH) * 1024, 0x00020000);
+    int woff = lane * 16;
+    auto wnext = [&]() __attribute__((always_inline)) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, woff, 0, 0);
+        woff += 1024;
+        return __builtin_bit_cast(half8, v);
+    };
+    half8 ring[DH];
+#pragma unroll
+    for (int k = 0; k < DH; ++k) ring[k] = wnext();
+    {   // input tile -> LDS (outside the picture: zeros = the padding)
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(p.x), 0, (int)((long)p.H * p.W * p.ldx * 2), 0x00020000);
+        const int G = p.kin / V, total = IH * IW * G;
+        const int iy0 = 2 * ty0 - p.pad, ix0 = 2 * tx0 - p.pad;
+        constexpr int U = 6;
+        for (int it0 = tid; it0 < total; it0 += U * NTHR_) {
+            u32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int it = it0 + u * NTHR_, hp = it / G, c = (it - hp * G) * V;
+                const int y = iy0 + hp / IW, x = ix0 + hp % IW;
+                const bool ok = it < total && y >= 0 && y < p.H && x >= 0 && x < p.W;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? ((y * p.W + x) * (int)p.ldx + c) * 2 : OOB, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int it = it0 + u * NTHR_, hp = it / G, c = (it - hp * G) * V;
+                const int r = hp / IW, col = hp % IW;
+                Vec16 w = __builtin_bit_cast(Vec16, v[u]);
+                if (p.in_q != nullptr) w = scale_vec<half_t>(w, p.in_q, c, p.in_qn);
+                if (it < total) *reinterpret_cast<Vec16*>(bufS + ((r * 2 + (col & 1)) * IWH + (col >> 1)) * lds_s + c) = w;
+            }
+        }
+    }
+    floatx16 acc[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    __syncthreads();
+
+    // B operand of output pixel (py, px) at tap (ky, kx), k-step s: row ((2 py + ky) * 2 + (kx & 1)) * IWH + px + (kx >> 1)
+    const int py = pl / TW_, px = pl % TW_;
+    const half_t* xb = bufS + ((2 * py) * 2 * IWH + px) * lds_s + 8 * hh;
+    auto tap_off = [&](int tap) __attribute__((always_inline)) {
+        const int ky = tap / p.k, kx = tap - ky * p.k;
+        return ((ky * 2 + (kx & 1)) * IWH + (kx >> 1)) * lds_s;
+    };
+    const int nb = p.kin / 128;                  // bodies of 8 k-steps per tap
+    half8 bc = *reinterpret_cast<const half8*>(xb + tap_off(0)), bn;
+    __builtin_amdgcn_sched_barrier(0);
+    for (int tap = 0; tap < taps; ++tap) {
+        const int toff = tap_off(tap), tnext = tap + 1 < taps ? tap_off(tap + 1) : toff;
+        for (int b = 0; b < nb; ++b) {
+#pragma unroll
+            for (int ss = 0; ss < 8; ++ss) {
+                int noff = toff + (8 * b + ss + 1) * 16;
+                if (ss == 7 && b + 1 == nb) noff = tap + 1 < taps ? tnext : toff + (8 * b + ss) * 16;
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) {
+                    if (i == 0) bn = *reinterpret_cast<const half8*>(xb + noff);
+                    acc[i] = mfma32(ring[ss * NTW + i], bc, acc[i]);
+                    ring[ss * NTW + i] = wnext();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                bc = bn;
+            }
+        }
+    }
+    __syncthreads();      // every wave has finished reading the input tile
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int chb = 32 * (cqw + 4 * i) + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const floatx4 bias = load_f4(p.b + chb + 8 * g);
+            floatx4 v = {acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+            lds_store_quad<half_t>(bufO, LDO, pl, chb + 8 * g, v + bias);
+        }
+    }
+    __syncthreads();
+    half_t* out = reinterpret_cast<half_t*>(p.out);
+#pragma unroll
+    for (int k = 0; k < G8; ++k) {
+        const int m = tid >> 3, c = ((tid & 7) + 8 * k) * V;
+        const int oy = ty0 + m / TW_, ox = tx0 + m % TW_;
+        if (oy < p.Ho && ox < p.Wo)
+            *reinterpret_cast<Vec16*>(out + ((long)oy * p.Wo + ox) * p.ldo + c) = *reinterpret_cast<const Vec16*>(bufO + m * LDO + c);
+    }
+}
+
 }  // namespace t128

@@ -952,6 +952,7 @@ struct dcvc_conv {
     DevBuf w, b;
     DevBuf w_t128;  // square 1x1 convs of width 256 / 320 / 384, fp16: the fragment stream for a fused launch behind a 128-pixel tail
     DevBuf w_c128[2];   // fp16, 3x3 s1 p1 convs: fragment streams of conv3x3_t128_kernel<1> (128-channel slices) and <2> (256)
+    DevBuf w_s2;        // fp16, stride-2 convs (2x2 p0, 3x3 p1) with 128 / 256 output channels: the stream of conv_s2_t32_kernel
 };
 
 namespace {
@@ -1080,16 +1081,17 @@ int pack_t128_rect(DevBuf& dst, int Kp, const std::function<float(int, int)>& W)
     return dst.upload(buf.data(), buf.size() * sizeof(half_t));
 }
 
-// 3x3 conv, Np / (128 ntw) slices x 4 quarters: fragments in (tap, k-step, tile) order; W(n, tap, ci) = physical row n
-inline int pack_t128_conv3x3(DevBuf& dst, int ntw, int Np, int Kp, const std::function<float(int, int, int)>& W)
+// a conv with `taps` taps, Np / (128 ntw) slices x 4 quarters: fragments in (tap, k-step, tile) order, `padf` dummy fragments
+// behind every quarter stream; W(n, tap, ci) = physical row n
+inline int pack_t128_conv(DevBuf& dst, int ntw, int taps, int padf, int Np, int Kp, const std::function<float(int, int, int)>& W)
 {
-    const int DH = 4 * ntw, slice = 128 * ntw;
-    const int ks = Kp / 16, LEN = 9 * ks * ntw + DH, nsl = Np / slice;
+    const int slice = 128 * ntw;
+    const int ks = Kp / 16, LEN = taps * ks * ntw + padf, nsl = Np / slice;
     std::vector<half_t> buf((size_t)nsl * 4 * LEN * 512, (half_t)0.f);
     for (int sl = 0; sl < nsl; ++sl)
         for (int cq = 0; cq < 4; ++cq) {
             size_t f = 0;
-            for (int tap = 0; tap < 9; ++tap)
+            for (int tap = 0; tap < taps; ++tap)
                 for (int s = 0; s < ks; ++s)
                     for (int i = 0; i < ntw; ++i, ++f) {
                         half_t* o = &buf[(((size_t)sl * 4 + cq) * LEN + f) * 512];
@@ -1516,6 +1518,35 @@ static bool c128_enabled()   // DCVC_C128=0: 3x3 convs by conv_kernel (A/B measu
 static int run_conv(const dcvc_conv* h, const ConvParams& cp, hipStream_t st)
 {
     if (h->dtype != DCVC_F16) return dispatch_conv<float, 2>(h, cp, st);
+    if (h->w_s2.p != nullptr && c128_enabled() && cp.src.c1 == 0 && (long)cp.Ho * cp.Wo < 12000) {     // (a workgroup streams all the weights for 32 pixels: small maps)
+        t128::ConvS2Params p{};
+        p.x = cp.src.x0;
+        p.ldx = cp.src.ld0;
+        p.H = cp.H;
+        p.W = cp.W;
+        p.Ho = cp.Ho;
+        p.Wo = cp.Wo;
+        p.kin = cp.src.c0;
+        p.k = cp.KH;
+        p.pad = cp.pad;
+        p.wt = h->w_s2.p;
+        p.b = cp.b;
+        p.in_q = cp.in_q;
+        p.in_qn = cp.in_qn;
+        p.out = cp.out;
+        p.ldo = cp.ldo;
+        const int ntw = cp.N / 128;
+        const size_t lds = t128::conv_s2_lds(p.kin, p.k, ntw);
+        const dim3 g(((cp.Ho + t128::S2_TH - 1) / t128::S2_TH) * ((cp.Wo + t128::S2_TW - 1) / t128::S2_TW));
+        int rc = ntw == 2 ? set_lds(t128::conv_s2_t32_kernel<2>, lds) : set_lds(t128::conv_s2_t32_kernel<1>, lds);
+        if (rc) return rc;
+        if (ntw == 2)
+            hipLaunchKernelGGL(t128::conv_s2_t32_kernel<2>, g, dim3(256), lds, st, p);
+        else
+            hipLaunchKernelGGL(t128::conv_s2_t32_kernel<1>, g, dim3(256), lds, st, p);
+        DCVC_LAUNCH_CHECK();
+        return 0;
+    }
     if (h->w_c128[0].p != nullptr && c128_enabled() && cp.src.c1 == 0 && cp.in_q == nullptr) {
         const int tiles = ((cp.H + t128::TH - 1) / t128::TH) * ((cp.W + t128::TW - 1) / t128::TW);
         // 256-channel slices at one workgroup per CU if that grid runs in one round, else 128-channel slices at two per CU
@@ -1795,9 +1826,15 @@ int dcvc_conv_create(int dtype, int cin, int cout, int kh, int kw, int stride, i
             const int nl = to_log(n);
             return (nl >= 0 && ci < cin) ? w[((size_t)nl * cin + ci) * taps + t] : 0.f;
         };
-        rc |= pack_t128_conv3x3(h->w_c128[0], 1, Np, Kp, WC);
-        rc |= pack_t128_conv3x3(h->w_c128[1], 2, Np, Kp, WC);
+        rc |= pack_t128_conv(h->w_c128[0], 1, 9, 4, Np, Kp, WC);
+        rc |= pack_t128_conv(h->w_c128[1], 2, 9, 8, Np, Kp, WC);
     }
+    if (rc == 0 && dtype == DCVC_F16 && stride == 2 && ((kh == 2 && kw == 2 && pad == 0) || (kh == 3 && kw == 3 && pad == 1)) &&
+        Kp % 128 == 0 && Kp <= 384 && (Np == 128 || Np == 256) && epilogue == DCVC_EPI_BIAS)
+        rc |= pack_t128_conv(h->w_s2, Np / 128, taps, 8 * (Np / 128), Np, Kp, [&](int n, int t, int ci) {
+            const int nl = to_log(n);
+            return (nl >= 0 && ci < cin) ? w[((size_t)nl * cin + ci) * taps + t] : 0.f;
+        });
     if (rc) return rc < 0 ? rc : dcvc::E_MEM;
     *out = h.release();
     return 0;

@@ -343,21 +343,22 @@ def test_conv(case, dtype):
     compare(got[:, :, :c_log], ref, dtype, f"conv {case}")
 
 
-def _conv3x3_out(cin, cout, epi, H, W):
+def _conv3x3_out(cin, cout, epi, H, W, k=3, stride=1, pad=1, scale=False):
     from opendcvc_amd import nn
-    rng = _rng(700 + cin + cout)
-    sd = {"m.weight": (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32),
+    rng = _rng(700 + cin + cout + k + stride)
+    sd = {"m.weight": (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32),
           "m.bias": (rng.standard_normal(cout) * 0.1).astype(np.float32)}
     x = rng.standard_normal((H, W, cin)).astype(np.float32)
-    conv = nn.Conv2d(sd, "m", torch.float16, 1, 1, EPI[epi])
-    out = conv(to_dev(x, conv.cin_p, torch.float16))
+    conv = nn.Conv2d(sd, "m", torch.float16, stride, pad, EPI[epi])
+    q = torch.from_numpy(rng.uniform(0.5, 1.5, cin).astype(np.float32)).cuda() if scale else None
+    out = conv(to_dev(x, conv.cin_p, torch.float16), in_scale=q)
     torch.cuda.synchronize()
     return out.float().cpu().numpy()
 
 
 def test_conv3x3_t128_equals_conv_kernel_bitwise(tmp_path):
-    """conv3x3_t128_kernel accumulates (tap, k) in conv_kernel's order: identical outputs with DCVC_C128=0 (a separate
-    process: the switch is read once)."""
+    """conv3x3_t128_kernel and conv_s2_t32_kernel (stride-2 convs, with and without the input scale, ragged edges) accumulate
+    (tap, k) in conv_kernel's order: identical outputs with DCVC_C128=0 (a separate process: the switch is read once)."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     outs = {}
@@ -365,7 +366,9 @@ def test_conv3x3_t128_equals_conv_kernel_bitwise(tmp_path):
         path = tmp_path / f"o{v}.npy"
         code = ("import sys, numpy as np; sys.path[:0] = [%r, %r, %r]; import test_gpu_layers as t; "
                 "np.save(%r, np.concatenate([t._conv3x3_out(128, 1024, 'shuffle', 68, 120).ravel(), "
-                "t._conv3x3_out(192, 256, 'bias', 21, 37).ravel()]))"
+                "t._conv3x3_out(192, 256, 'bias', 21, 37).ravel(), "
+                "t._conv3x3_out(256, 256, 'bias', 136, 240, 2, 2, 0, True).ravel(), t._conv3x3_out(256, 128, 'bias', 37, 51, 3, 2, 1).ravel(), "
+                "t._conv3x3_out(128, 128, 'bias', 13, 18, 2, 2, 0).ravel(), t._conv3x3_out(368, 256, 'bias', 9, 7, 3, 2, 1, True).ravel()]))"
                 % (here, os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), str(path)))
         subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, DCVC_C128=v))
         outs[v] = np.load(path)
