@@ -119,6 +119,10 @@ class _CaptureScope:
 CAPTURE_GUARD = _CaptureGuard()
 
 
+# DCVC_NO_FORK=1: no second stream inside a run (the temporal prior encoder then runs behind the hyper decoder)
+_FORK = os.environ.get("DCVC_NO_FORK") != "1"
+
+
 class GraphCache:
     """Fixed runs of kernel launches, captured once per key as a HIP graph and replayed afterwards.
 
@@ -452,6 +456,7 @@ class DMC(CompressionModel):
         self._pending = None     # decoder, deferred output: the reconstruction network of the previous frame still to run
         self._stream_pending = None   # encoder, deferred stream: symbols of the previous frame still to be entropy coded
         self._stream_parity = 0
+        self._branch = None      # second HIP stream for the branches inside a run (_prior_params)
 
     def _build_layers(self, sd, dt):
         D, C2, R = L.DepthConvBlock, L.Conv2d, L.ResidualBlockWithStride2
@@ -545,17 +550,35 @@ class DMC(CompressionModel):
         outs = L.dcb_chain(blocks + self._layers["fe2"], self._fe_input(variant, ref_buf), return_all=True)
         return outs[len(blocks) - 1], outs[-1]
 
+    def _branch_stream(self, device):
+        """second stream of this model for branches inside a run (one per model: encoder and decoder replay concurrently)"""
+        if self._branch is None:
+            self._branch = torch.cuda.Stream(device)
+        return self._branch
+
     def _prior_params(self, z_hat, x1, q_feature, yh, yw):
         """res_prior_param_decoder (video_model.py:279-286) -> [yh, yw, 384] = q_dec | scales | means.
         x1, q_feature: temporal_prior_encoder reads ctx_t = x1 * q_feature (same values as the stand-alone product)"""
         n = self._layers
         cat = torch.empty((yh, yw, 3 * arch.DMC_CH_Y), dtype=z_hat.dtype, device=z_hat.device)
+        # The hyper decoder works on 17x30 / 34x60 maps (kernels of 16 - 64 workgroups that leave the GPU empty) and the
+        # temporal prior encoder does not depend on it: the two run side by side, the temporal branch on a second stream
+        # (a fork / join of the captured run; its own scratch: nn.Scratch is per stream).  Same kernels, same values.
+        main = torch.cuda.current_stream()
+        side = self._branch_stream(z_hat.device) if _FORK else None
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                n["temporal"](x1, in_scale=q_feature, out=cat[:, :, arch.DMC_CH_Y:])
         h = n["hyper_dec"][1](n["hyper_dec"][0](z_hat))
         if h.shape[0] == yh and h.shape[1] == yw:
             n["hyper_dec"][2](h, out=cat[:, :, :arch.DMC_CH_Y])
         else:
             self._crop(n["hyper_dec"][2](h), yh, yw, out=cat[:, :, :arch.DMC_CH_Y])
-        n["temporal"](x1, in_scale=q_feature, out=cat[:, :, arch.DMC_CH_Y:])
+        if side is not None:
+            main.wait_stream(side)
+        else:
+            n["temporal"](x1, in_scale=q_feature, out=cat[:, :, arch.DMC_CH_Y:])
         return L.dcb_chain(n["fusion"], cat, then_conv=n["fusion_out"])          # (the last conv runs in the last tail)
 
     def _spatial_prior(self, y_hat, params):
