@@ -512,6 +512,9 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
                         if (idx == N4 && t == PTW - 1) bias_load(jb);                // the next chunk's, into the same registers
                     }
                     if constexpr (GATE) {
+#ifdef DCVC_DIAG
+                        if (!(p.ablate & 64))        // timing experiment: the FFN without its gate (wrong results)
+#endif
 #pragma unroll
                         for (int pp = 0; pp < PPS; ++pp)
                             if (m * PPS + pp < NPIECE) gate_piece(ug, vcur, m * PPS + pp);
