@@ -399,8 +399,10 @@ def main():
             "gop_weighted_note": "frames/s of one 32-frame GOP = 32 / (t_I + 31 t_P), t_P = median interval between completed "
                                  "frames of the timed window (%.3f ms), t_I = the rest of the window per I frame (%.3f ms): "
                                  "independent of --steps" % (1e3 * t_p, 1e3 * t_i),
-            "config": {"workload": "DCVC-RT inter-coding, %s YUV420 32-frame GOP, single q (qp 32), one stream per MI355X "
-                                   "(BASELINE.json configs[%d])" % (("1080p", 1) if (WIDTH, HEIGHT) == (1920, 1080) else (args.frame, 3)),
+            "config": {"workload": "DCVC-RT inter-coding, %s YUV420 32-frame GOP, single q (qp 32), one stream per MI355X (%s)"
+                                   % (("1080p", "BASELINE.json configs[1]") if (WIDTH, HEIGHT) == (1920, 1080)
+                                      else (args.frame, "BASELINE.json configs[3]") if (WIDTH, HEIGHT) == (3840, 2160)
+                                      else (args.frame, "not a BASELINE.json configuration")),
                        "frame": "%dx%d padded to %dx%d" % (WIDTH, HEIGHT, WIDTH + (-WIDTH) % 16, HEIGHT + (-HEIGHT) % 16), "intra_period": GOP, "i_frames_timed": state["n_i"],
                        "i_frame_share_timed": round(state["n_i"] / float(K), 4), "i_frame_share_gop": round(1.0 / GOP, 4),
                        "alignment_frames": align, "cpus_per_rank": len(cpus) if cpus else len(os.sched_getaffinity(0)),
