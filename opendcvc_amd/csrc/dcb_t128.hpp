@@ -251,8 +251,8 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
         return *reinterpret_cast<const half8*>(xb + t * 32 * LDX + s * 16);
     };
 
-    // W2 d, one MFMA per slot.  (G2OV: the four k-steps (64 channels) of slab s - 1 issued between the multiply-adds of slab s
-    // of the depthwise stage - built, measured slower, switched off)
+    // W2 d, one MFMA per slot (runs behind the depthwise stage; its k-steps spread between that stage's multiply-adds were
+    // built and measured slower - 45.8 against 45.0 us, docs/experiments.md)
     floatx16 acc[NTW][PTW];
     half8 g2b[PTW];
     auto gemm2_slot = [&](int s, int q) __attribute__((always_inline)) {      // MFMA q of k-step s of W2 d
@@ -271,11 +271,7 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
         }
         if (t == PTW - 1) ring[k] = wload();
     };
-    constexpr bool G2OV = false;                        // measured (C=256, 136x240): the depthwise slabs get slower by more than
-                                                        // W2's 3 K cycles (ring refills and fragment reads in a stage that
-                                                        // lives on its LDS / vector issue) - 45.0 us without, 45.8 us with
     constexpr int G2Q = NTW * PTW;                      // MFMAs per k-step
-    constexpr int G2SLAB = (DW_SLAB / 16) * G2Q;        // MFMAs per slab (4 k-steps)
     // ---- depthwise 3x3 (zero padding) + bias -> d in bufX.  A slab goes registers -> one of two LDS halo buffers
     // (bufV region) -> taps; one barrier per slab.
     {
@@ -291,7 +287,7 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
                 if (hp < HALO) *reinterpret_cast<Vec16*>(hb + hp * LDS_S + dcs) = pre[slab][k];
             }
             if (slab == nslab - 2) ident_fetch();   // (registers of the first slabs are free again; two slabs of time to arrive)
-            if (slab == (G2OV ? 0 : nslab - 1)) {   // first turn of the weight ring: lands underneath this slab
+            if (slab == nslab - 1) {                // first turn of the weight ring: lands underneath this slab
 #pragma unroll
                 for (int k = 0; k < D; ++k) ring[k] = wload();
             }
@@ -315,17 +311,7 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        fma_vec16<half_t>(tv[e + ky][kx], wtap[ky * 3 + kx], sacc);
-                        // (18 tap groups per slab; the previous slab's W2 MFMAs spread over them)
-                        const int tg = e * 9 + ky * 3 + kx, m0 = tg * G2SLAB / 18, m1 = (tg + 1) * G2SLAB / 18;
-                        if (G2OV && slab > 0) {
-#pragma unroll
-                            for (int mm = 0; mm < G2SLAB; ++mm)
-                                if (mm >= m0 && mm < m1) gemm2_slot((slab - 1) * (DW_SLAB / 16) + mm / G2Q, mm % G2Q);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
+                    for (int kx = 0; kx < 3; ++kx) fma_vec16<half_t>(tv[e + ky][kx], wtap[ky * 3 + kx], sacc);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     sacc[j] = sacc[j] + bd0[j];
@@ -359,9 +345,9 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
     };
     ebias_load(p.b2);
 
-    // ---- W2 d: the k-steps of the last slab (the others ran inside the depthwise stage), or all of them
+    // ---- W2 d
 #pragma unroll
-    for (int mm = G2OV ? (nslab - 1) * G2SLAB : 0; mm < nslab * G2SLAB; ++mm) {
+    for (int mm = 0; mm < KS * G2Q; ++mm) {
         gemm2_slot(mm / G2Q, mm % G2Q);
         __builtin_amdgcn_sched_barrier(0);
     }
