@@ -76,6 +76,21 @@ def test_one_rate_point_end_to_end(tmp_path):
     assert 0 < log["ave_all_frame_psnr"] < 60 and log["ave_all_frame_msssim"] == 0      # (untrained synthetic weights: single-digit dB)
 
 
+def test_ramped_qp_tables_leave_the_other_weights_alone():
+    """weights.make_state_dict(q_ramp=True) (the weights of tests/golden/sweep_ramp.json): only the per-qp tables differ from
+    the default draw, they span 16:1 over qp, encoder-side tables rise and decoder-side ones fall."""
+    from opendcvc_amd import weights
+    for name in ("dmc", "dmci"):
+        a, b = weights.make_state_dict(name, 1234), weights.make_state_dict(name, 1234, q_ramp=True)
+        assert list(a) == list(b)
+        changed = [k for k in a if not np.array_equal(a[k], b[k])]
+        assert changed and all(k.startswith("q_") for k in changed), changed
+        for k in changed:
+            lo, hi = float(b[k][0].mean()), float(b[k][63].mean())
+            ratio = hi / lo if not ("dec" in k or "recon" in k) else lo / hi
+            assert 12.0 < ratio < 20.0, (k, lo, hi)
+
+
 def _nets(dtype, q_ramp=False):
     import torch
     from opendcvc_amd import weights
