@@ -1,5 +1,8 @@
 # Developer script: the measurements kept under profiles/ (run on the GPU box from the repo root).
 #   bash tools/final_measure.sh r03
+# Companion scripts (separate calls, each a few GPU-minutes): tools/launches_measure.sh (per-pair tables with DCVC_T32 on / off),
+# tools/pmc_g32.sh (counters of the 32-pixel tail), tools/bench_stats.sh (per-kernel stats of a bench run), tools/t32_check.sh /
+# h128_check.sh / conv_mt_check.sh (A/B timings of the round-3 kernels), tools/dec_profile.py (host profile of the decoder).
 set -e
 R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
