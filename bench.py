@@ -133,7 +133,8 @@ def window_start(steps):
 def measure(run, steps, warmup, world, device, sync):
     """The timed region of the driver contract: `warmup` (+ the frames needed to place the window in the GOP) untimed
     steps, barrier + device sync, EXACTLY `steps` steps, barrier + device sync, MAX over ranks.
-    run(n, timed) codes n frames; sync() waits for the device.  Returns (elapsed seconds, alignment frames)."""
+    run(n, timed) codes n frames; sync() waits for the device.  Returns (elapsed seconds = MAX over ranks, alignment
+    frames, this rank's own elapsed seconds before the closing barrier)."""
     align = (window_start(steps) - warmup) % GOP
     sync()
     run(warmup + align, False)
@@ -141,9 +142,11 @@ def measure(run, steps, warmup, world, device, sync):
     sync()
     t0 = time.perf_counter()
     run(steps, True)
+    sync()
+    local = time.perf_counter() - t0          # this rank's own K steps (per-rank fps on the line)
     dist_utils.barrier(world)
     sync()
-    return dist_utils.max_over_ranks(time.perf_counter() - t0, device, world), align
+    return dist_utils.max_over_ranks(time.perf_counter() - t0, device, world), align, local
 
 
 def cpu_model():
@@ -255,6 +258,64 @@ def exact_mode_leg(device, world, rank, frames16):
                     "CPU oracle (tests/test_gpu_codec.py); 5 steady P frames, sequential, each frame synchronised"}
 
 
+def self_launch(n_gpus, argv):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves, one process per GPU, the way
+    the reference harness starts its own workers (test_video.py:381-395,439-442: a spawned pool, worker n on GPU n) -
+    here as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`, a CHILD process
+    (never an exec: this parent has imported torch but made no GPU call, and it stays that way).  The ranks' stdout /
+    stderr are ours; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")                 # (the launcher would set and announce it otherwise)
+    return subprocess.call(cmd, env=env)
+
+
+def stub_main(args, world, rank, local):
+    """DCVC_BENCH_STUB=1 - a control-flow rehearsal for the CPU tests, NOT a measurement and never a fallback: the same
+    launcher, rank checks, CPU pinning, weight broadcast, measure() and rank-0 line as the real run, on the gloo backend
+    with a stub in place of the codec (rank r sleeps (r + 1) ms per frame).  The line says so in `data` and `metric`."""
+    import torch.distributed as dist
+    cpus = dist_utils.pin_rank_threads(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else None
+    device = torch.device("cpu")
+    if world > 1:
+        dist.init_process_group("gloo")
+    sd = weights.make_state_dict("dmc", 1234) if rank == 0 else None
+    got = dist_utils.broadcast_state_dict("dmc", sd, device, rank, world)
+    digest = float(sum(float(np.asarray(v, np.float64).sum()) for v in got.values()))
+    state = {"n": 0}
+
+    def run(n, timed):
+        state["n"] += n
+        time.sleep(0.001 * (rank + 1) * n)
+
+    elapsed, align, mine = measure(run, args.steps, args.warmup, world, device, lambda: None)
+    fps = dist_utils.gather_over_ranks(args.steps / mine, device, world)
+    digests = dist_utils.gather_over_ranks(digest, device, world)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "STUB control-flow rehearsal (gloo, sleeping stub codec) - not a measurement",
+            "value": round(world * args.steps / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
+            "rank_fps": {"min": round(min(fps), 3), "max": round(max(fps), 3)},
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "weights_identical_on_all_ranks": len(set(digests)) == 1,
+            "config": {"workload": "stub", "alignment_frames": align, "frames_run": state["n"],
+                       "cpus_per_rank": len(cpus) if cpus else len(os.sched_getaffinity(0)),
+                       "cpus_granted": dist_utils.cpus_granted(int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,9 +331,19 @@ def main():
 
     global HEIGHT, WIDTH
     WIDTH, HEIGHT = (int(v) for v in args.frame.lower().split("x"))
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: start the N ranks (child processes) and hand their exit code on
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s): one rank per GPU, --gpus N must equal "
+                         "WORLD_SIZE" % (args.gpus, world))
+    if os.environ.get("DCVC_BENCH_STUB") == "1":
+        return stub_main(args, world, rank, local)
     # one process per GPU: keep this rank's threads (2 pipeline threads + the rANS workers) on its share of the cores,
     # those of its GPU's NUMA node when sysfs tells - before anything touches the GPU
     cpus = dist_utils.pin_rank_threads(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else None
@@ -326,7 +397,8 @@ def main():
     # Placement of the timed window in the GOP (the encoder codes an I frame whenever its frame counter is a multiple
     # of 32): whole GOPs start on an I frame; a shorter window gets one I frame in its middle - never a P-only window.
     K = args.steps
-    elapsed, align = measure(run_pipelined, K, args.warmup, world, device, torch.cuda.synchronize)
+    elapsed, align, mine = measure(run_pipelined, K, args.warmup, world, device, torch.cuda.synchronize)
+    rank_fps = dist_utils.gather_over_ranks(K / mine, device, world)         # every rank's own frames/s (rank 0 reports)
     assert state["i"] % GOP == (window_start(K) + K) % GOP
     assert state["j"] == args.warmup + align + K
     assert state["n_i"] >= max(1, K // GOP), "the timed window must contain I frames at the GOP's rate"
@@ -395,6 +467,9 @@ def main():
             "value": round(value, 3), "unit": "frames/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": round(seq_value / base, 4), "dtype": "f16", "data": "synthetic",
+            "rank_fps": {"min": round(min(rank_fps), 3), "max": round(max(rank_fps), 3),
+                         "note": "each rank's own K timed frames / its own time (before the closing barrier)"},
+            "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
             "gop_weighted_value": round(N * gop_weighted, 3),
             "gop_weighted_note": "frames/s of one 32-frame GOP = 32 / (t_I + 31 t_P), t_P = median interval between completed "
                                  "frames of the timed window (%.3f ms), t_I = the rest of the window per I frame (%.3f ms): "

@@ -127,6 +127,17 @@ def max_over_ranks(value, device, world):
     return float(t.item())
 
 
+def gather_over_ranks(value, device, world):
+    """every rank's `value` (a float), as a list in rank order, on every rank"""
+    if world == 1:
+        return [float(value)]
+    import torch.distributed as dist
+    mine = torch.tensor([value], device=device, dtype=torch.float64)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
 def barrier(world):
     if world > 1:
         import torch.distributed as dist

@@ -76,7 +76,8 @@ def _bench_worker(rank, world, port, q):
 
     steps, warmup = 20, 5
     t0 = time.perf_counter()
-    elapsed, align = bench.measure(run, steps, warmup, world, torch.device("cpu"), lambda: None)
+    elapsed, align, mine = bench.measure(run, steps, warmup, world, torch.device("cpu"), lambda: None)
+    assert 0.0 < mine <= elapsed
     wall = time.perf_counter() - t0
     q.put((rank, elapsed, align, calls, sorted(cpus), wall))
     dist.destroy_process_group()
@@ -130,3 +131,46 @@ def test_visible_devices_remap_disables_the_sysfs_order(monkeypatch):
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "3,1")
     monkeypatch.setattr(dist_utils, "gpu_local_cpus", lambda *a, **k: (_ for _ in ()).throw(AssertionError("sysfs order used")))
     assert dist_utils.rank_cpus(1, 2, list(range(8)), quota=None) == [4, 5, 6, 7]
+
+
+def _run_bench(argv, extra_env=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DCVC_BENCH_STUB="1", **(extra_env or {}))
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, [json.loads(ln) for ln in lines]
+
+
+def test_bench_gpus2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` - the shape of the driver's command - with no launcher around it: bench.py starts the two
+    ranks as a child torchrun (gloo + the stub codec here: DCVC_BENCH_STUB=1), rank 0 prints ONE line with n_gpus 2."""
+    p, lines = _run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 20 and out["warmup"] == 5
+    assert out["data"] == "stub" and out["weights_identical_on_all_ranks"] is True
+    # rank r sleeps (r + 1) ms per frame: the job runs at the slower rank's pace, both ranks count
+    assert out["rank_fps"]["min"] < out["rank_fps"]["max"]
+    assert out["rank_fps"]["min"] <= 500.0 * 1.05
+    assert out["value"] <= 2 * out["rank_fps"]["min"] * 1.05
+    assert out["config"]["alignment_frames"] == (22 - 5) % 32 and out["config"]["frames_run"] == 5 + 17 + 20
+
+
+def test_bench_gpus1_stays_one_process():
+    p, lines = _run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 1 and lines[0]["rccl_ranks"] == 1
+
+
+def test_bench_rejects_world_size_mismatch():
+    """a launcher that started a different number of ranks than --gpus says: refuse, do not print a mislabelled line"""
+    p, lines = _run_bench(["--gpus", "4"], extra_env=dict(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert p.returncode != 0 and not lines
+    assert "--gpus 4" in p.stderr
