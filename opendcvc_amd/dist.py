@@ -58,6 +58,9 @@ def cpus_granted(local_world, allowed=None, quota="auto"):
     return max(1, n // max(1, local_world))
 
 
+MIN_RANK_CPUS = 4        # encoder thread, decoder thread, one rANS worker each at least
+
+
 def rank_cpus(local_rank, local_world, allowed=None, gpu_cpus=None, quota="auto"):
     """The CPU set rank `local_rank` of `local_world` ranks on this node should run on: the allowed CPUs local to its
     GPU's NUMA node, divided evenly between the ranks whose GPUs share that node; without topology information (or
@@ -68,8 +71,10 @@ def rank_cpus(local_rank, local_world, allowed=None, gpu_cpus=None, quota="auto"
         remapped = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
         gpu_cpus = [] if remapped else gpu_local_cpus()
     # A cgroup CPU quota below the mask (16 CPUs of time on a 256-thread mask): a rank keeps its threads on as many CPUs
-    # of its slice as its share of the quota is worth - spreading them over the whole slice buys no CPU time.
-    keep = cpus_granted(local_world, allowed, quota)
+    # of its slice as its share of the quota is worth - spreading them over the whole slice buys no CPU time - but never on
+    # fewer than MIN_RANK_CPUS: the quota limits CPU time, not parallelism, and a rank runs two pipeline threads plus the
+    # rANS workers of two coders, whose point is to overlap each other.
+    keep = max(cpus_granted(local_world, allowed, quota), MIN_RANK_CPUS)
     part = None
     if len(gpu_cpus) >= local_world and all(gpu_cpus[r] & set(allowed) for r in range(local_world)):
         mine = sorted(gpu_cpus[local_rank] & set(allowed))

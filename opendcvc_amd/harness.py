@@ -281,6 +281,48 @@ def worker_gpu(process_name, gpu_num):
     return idx % gpu_num if gpu_num > 0 else -1
 
 
+MIN_WORKER_CPUS = 3      # codec thread + the two rANS worker threads of a 1080p stream
+
+
+def worker_cpus(idx, workers, allowed, quota=None):
+    """CPU set of pool worker `idx` of `workers`: its contiguous slice of the allowed CPUs; with a cgroup quota below the
+    mask only as many CPUs of the slice as its share of the quota is worth (spreading wider buys no CPU time) - but never
+    fewer than MIN_WORKER_CPUS (neighbouring workers then share some)."""
+    n = len(allowed)
+    lo, hi = idx * n // workers, (idx + 1) * n // workers
+    if quota is not None:
+        hi = min(hi, lo + max(MIN_WORKER_CPUS, quota // workers))
+    if hi - lo < MIN_WORKER_CPUS:
+        lo = max(0, min(lo, n - MIN_WORKER_CPUS))
+        hi = min(n, lo + MIN_WORKER_CPUS)
+    return allowed[lo:hi] or allowed
+
+
+def visible_gpu_ids(env=None):
+    """The physical device ids the parent process was given (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES, a scheduler's assignment), in order; None if none is set.  Workers index THIS list
+    (the reference's --cuda_idx, test_video.py:389-393) - worker n must not land on physical GPU n when the job was
+    given GPUs 4,5."""
+    env = os.environ if env is None else env
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(var)
+        if v:
+            ids = [t.strip() for t in v.split(",") if t.strip()]
+            if ids:
+                return ids
+    return None
+
+
+def count_gpus():
+    """number of AMD GPUs the workers may use, without a HIP call in the parent: the visible-devices list if there is
+    one, else the render nodes in sysfs"""
+    ids = visible_gpu_ids()
+    if ids is not None:
+        return len(ids)
+    from . import dist
+    return len(dist.gpu_local_cpus())
+
+
 def _init_worker(opts, gpu_num):
     """Runs once in every spawned worker (test_video.py:381-414): picks the GPU, pins the process, loads both models."""
     import multiprocessing
@@ -289,10 +331,14 @@ def _init_worker(opts, gpu_num):
         ids = opts.get("gpu_ids")
         os.environ["HIP_VISIBLE_DEVICES"] = str(ids[gpu] if ids else gpu)     # before the first GPU call of the process
     workers_here = max(1, opts.get("workers", 1))
-    try:      # every worker gets its share of the CPUs the cgroup grants (two codec threads + the rANS workers each)
+    try:
+        # Every worker stays on its slice of the allowed CPUs, never on fewer than MIN_WORKER_CPUS of them: a worker runs the
+        # codec thread plus two rANS worker threads, and a cgroup cpu.max quota limits CPU TIME, not parallelism - cutting a
+        # slice down to quota // workers (one CPU at -w 16 on a 16-CPU grant) would put the host coder behind the kernel
+        # launches it is meant to overlap.  Slices of neighbouring workers overlap when there are fewer CPUs than that.
         from . import dist
-        os.sched_setaffinity(0, dist.rank_cpus((int(multiprocessing.current_process().name.rsplit("-", 1)[1]) - 1) % workers_here,
-                                               workers_here, gpu_cpus=[]))
+        idx = (int(multiprocessing.current_process().name.rsplit("-", 1)[1]) - 1) % workers_here
+        os.sched_setaffinity(0, worker_cpus(idx, workers_here, sorted(os.sched_getaffinity(0)), dist.cgroup_cpu_quota()))
     except (OSError, ValueError, ImportError):
         pass
     mod, fn = opts.get("codec", "opendcvc_amd.harness:default_nets").split(":")
@@ -376,6 +422,9 @@ def main(argv=None):
                     "sequence x rate point becomes a job on the worker pool (reference: test_video.py --test_config)")
     ap.add_argument("-w", "--worker", type=int, default=1, help="worker processes (may exceed --gpus)")
     ap.add_argument("--gpus", type=int, default=None, help="GPUs to spread the workers over (default: all visible)")
+    ap.add_argument("--gpu-ids", type=lambda v: [t for t in v.split(",") if t], default=None,
+                    help="physical device ids for the workers, comma separated (reference: --cuda_idx); default: the "
+                         "parent's HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES list, else 0..gpus-1")
     ap.add_argument("--force-root-path")
     ap.add_argument("--force-frame-num", type=int, default=-1)
     ap.add_argument("--force-intra-period", type=int, default=-1)
@@ -402,8 +451,11 @@ def main(argv=None):
     if args.test_config:
         with open(args.test_config) as f:
             config = json.load(f)
-        gpus = args.gpus if args.gpus is not None else torch.cuda.device_count()
-        opts = dict(rate_num=args.rate_num, qp_i=args.qp_i, qp_p=args.qp_p, force_root_path=args.force_root_path,
+        gpu_ids = args.gpu_ids or visible_gpu_ids()
+        gpus = args.gpus if args.gpus is not None else (len(gpu_ids) if gpu_ids else count_gpus())
+        if gpu_ids and gpus > len(gpu_ids):
+            ap.error("--gpus %d but only %d device ids are given / visible (%s)" % (gpus, len(gpu_ids), ",".join(gpu_ids)))
+        opts = dict(gpu_ids=gpu_ids, rate_num=args.rate_num, qp_i=args.qp_i, qp_p=args.qp_p, force_root_path=args.force_root_path,
                     force_frame_num=args.force_frame_num, force_intra_period=args.force_intra_period,
                     reset_interval=args.reset_interval, model_i=args.model_i, model_p=args.model_p,
                     force_zero_thres=args.force_zero_thres, fp32=args.fp32, stream_path=args.stream_path,

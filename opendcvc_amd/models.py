@@ -119,6 +119,26 @@ class _CaptureScope:
 CAPTURE_GUARD = _CaptureGuard()
 
 
+class _ModelScope:
+    """One per-frame call of one model: inside CAPTURE_GUARD.frame(), and the only thread inside this model instance.
+    A model's captured runs share its scratch buffers, its branch stream and its persistent staging (like the reference's
+    models share their DPB): two host threads may drive two DIFFERENT instances concurrently (the two-stage pipeline does),
+    never the same one - that is refused here instead of corrupting a layer's scratch between two of its kernels."""
+
+    def __init__(self, model):
+        self.m = model
+
+    def __enter__(self):
+        if not self.m._owner.acquire(blocking=False):
+            raise DcvcError("this model instance is already inside compress / decompress on another host thread: one "
+                            "instance is driven by one thread at a time (use one instance per thread; they may share a GPU)")
+        CAPTURE_GUARD._enter()
+
+    def __exit__(self, *exc):
+        CAPTURE_GUARD._exit()
+        self.m._owner.release()
+
+
 # DCVC_NO_FORK=1: no second stream inside a run (the temporal prior encoder then runs behind the hyper decoder)
 _FORK = os.environ.get("DCVC_NO_FORK") != "1"
 
@@ -192,6 +212,11 @@ class CompressionModel(tnn.Module):
         self._q = {}
         self._graphs = GraphCache()
         self._persist = {}
+        import threading
+        self._owner = threading.RLock()           # see _ModelScope
+
+    def _frame(self):
+        return _ModelScope(self)
 
     # ---- static helpers used by test_video.py
     @staticmethod
@@ -223,8 +248,16 @@ class CompressionModel(tnn.Module):
         pre = "bit_estimator_z."
         params = {k[len(pre):]: v.detach().float().cpu() for k, v in sd.items() if k.startswith(pre)}
         if self._z_master is None and any(v.dtype != torch.float32 for k, v in sd.items() if k.startswith(pre)):
-            raise DcvcError("update(): only fp16 copies of bit_estimator_z are left (the model was converted without "
-                            "half() / load_state_dict of fp32 tensors): the z CDF tables would differ from the reference's")
+            # Only fp16 copies of bit_estimator_z exist (a half checkpoint, or another model's .half() state_dict): the
+            # tables are built from what there is - exactly what the reference does with such a model - and will differ
+            # from those of the fp32 checkpoint.  DCVC_STRICT_Z_TABLES=1 turns the warning into an error.
+            msg = ("update(): only fp16 copies of bit_estimator_z are left (half checkpoint, or converted without half() / "
+                   "load_state_dict of fp32 tensors): the z CDF tables are built from the fp16 values and may differ from "
+                   "the tables of the fp32 checkpoint - streams then decode only with a decoder built the same way")
+            if os.environ.get("DCVC_STRICT_Z_TABLES") == "1":
+                raise DcvcError(msg)
+            import warnings
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
         params.update(self._z_master or {})       # fp32 master values: same tables before and after the conversion
         self._z_group = self.entropy_coder.add_cdf(*entropy.factorized_cdf_tables(params, self.qp_total, self.z_channel))
 
@@ -241,12 +274,22 @@ class CompressionModel(tnn.Module):
     def load_state_dict(self, state_dict, *args, **kwargs):
         """The incoming checkpoint's fp32 bit_estimator_z.* tensors are kept as the master copy for the CDF tables, so a
         model that is already half() - or gets converted by .to(torch.float16) / _apply instead of .half() - still
-        builds the reference's tables (the reference builds them in fp32 before .half(), test_video.py:398-404)."""
+        builds the reference's tables (the reference builds them in fp32 before .half(), test_video.py:398-404).
+        The master is replaced only after the load has succeeded; a dict that carries only fp16 z tensors keeps the existing
+        master if those tensors are its fp16 rounding (the model's own .half() state_dict coming back), else drops it."""
         pre = "bit_estimator_z."
-        master = {k[len(pre):]: v.detach().float().cpu().clone() for k, v in state_dict.items()
-                  if k.startswith(pre) and torch.is_tensor(v) and v.dtype == torch.float32}
-        self._z_master = master or None
-        return super().load_state_dict(state_dict, *args, **kwargs)
+        z_in = {k[len(pre):]: v for k, v in state_dict.items() if k.startswith(pre) and torch.is_tensor(v)}
+        res = super().load_state_dict(state_dict, *args, **kwargs)
+        master = {k: v.detach().float().cpu().clone() for k, v in z_in.items() if v.dtype == torch.float32}
+        if master:
+            self._z_master = master
+        elif z_in and self._z_master is not None:
+            same = set(z_in) == set(self._z_master) and all(
+                z_in[k].dtype == torch.float16 and z_in[k].shape == self._z_master[k].shape and
+                torch.equal(z_in[k].detach().cpu(), self._z_master[k].half()) for k in z_in)
+            if not same:
+                self._z_master = None
+        return res
 
     def set_use_two_entropy_coders(self, use_two_entropy_coders):
         self.entropy_coder.set_use_two_entropy_coders(use_two_entropy_coders)
@@ -302,13 +345,11 @@ class CompressionModel(tnn.Module):
         return b
 
     def _picture_out(self, head):
-        """PixelShuffle(8) + clamp of the last conv's output into one of TWO alternating picture buffers, launched outside
-        the captured run (whose own output buffer would be overwritten by the next frame): the returned picture stays
-        valid until the second following frame has been produced - no copy (the reference returns a fresh tensor)."""
-        H, W, _, _ = L._geom(head)
-        self._pic_parity = getattr(self, "_pic_parity", 0) ^ 1
-        buf = self._buffer(f"picture_{self._pic_parity}", (1, 3, H * 8, W * 8), head.dtype, head.device)
-        return self._shuffle8_clamp(head, out=buf)
+        """PixelShuffle(8) + clamp of the last conv's output into a FRESH tensor, launched outside the captured run (whose own
+        output buffer is overwritten by the next frame).  The reference returns a fresh tensor per frame and callers keep
+        them (a sequence's pictures for the PSNR, the DPB): no ring of picture buffers - the kernel writes the new tensor
+        directly, so there is no copy either, and the allocator hands the block back once the caller drops the picture."""
+        return self._shuffle8_clamp(head)
 
     def _thres(self):
         return -1.0 if self.force_zero_thres is None else float(self.force_zero_thres)
@@ -551,7 +592,9 @@ class DMC(CompressionModel):
         return outs[len(blocks) - 1], outs[-1]
 
     def _branch_stream(self, device):
-        """second stream of this model for branches inside a run (one per model: encoder and decoder replay concurrently)"""
+        """second stream of this model for branches inside a run.  One per model instance, like the scratch its kernels
+        use (nn.Scratch is per stream): safe because one instance is inside one frame call at a time (_ModelScope) - the
+        encoder's and the decoder's instances, which do run concurrently, each have their own."""
         if self._branch is None:
             self._branch = torch.cuda.Stream(device)
         return self._branch
@@ -619,10 +662,11 @@ class DMC(CompressionModel):
             pd["x_hat"] = self._picture_out(head)
 
     def finish_output(self):
-        """finish_output under CAPTURE_GUARD.frame(): called directly from two host threads (the reference-compatible API, not only
-        through SequenceEncoder / SequenceDecoder), a frame never synchronises or allocates while another thread's
-        GraphCache.run is capturing.  The scope is re-entrant per thread."""
-        with CAPTURE_GUARD.frame():
+        """finish_output inside this model's frame scope (_ModelScope): while another thread's GraphCache.run is capturing, a frame
+        neither synchronises nor allocates (so two model INSTANCES may be driven from two host threads, through this
+        reference-compatible API as well as through SequenceEncoder / SequenceDecoder); a second thread entering the SAME
+        instance is refused.  The scope is re-entrant per thread."""
+        with self._frame():
             return self._finish_output_unguarded()
 
     def _finish_output_unguarded(self):
@@ -669,10 +713,11 @@ class DMC(CompressionModel):
         return ec.get_encoded_stream()
 
     def finish_stream(self):
-        """finish_stream under CAPTURE_GUARD.frame(): called directly from two host threads (the reference-compatible API, not only
-        through SequenceEncoder / SequenceDecoder), a frame never synchronises or allocates while another thread's
-        GraphCache.run is capturing.  The scope is re-entrant per thread."""
-        with CAPTURE_GUARD.frame():
+        """finish_stream inside this model's frame scope (_ModelScope): while another thread's GraphCache.run is capturing, a frame
+        neither synchronises nor allocates (so two model INSTANCES may be driven from two host threads, through this
+        reference-compatible API as well as through SequenceEncoder / SequenceDecoder); a second thread entering the SAME
+        instance is refused.  The scope is re-entrant per thread."""
+        with self._frame():
             return self._finish_stream_unguarded()
 
     def _finish_stream_unguarded(self):
@@ -682,10 +727,11 @@ class DMC(CompressionModel):
         return None if job is None else self._code_symbols(job)
 
     def compress(self, x, qp, defer_stream=False):
-        """compress under CAPTURE_GUARD.frame(): called directly from two host threads (the reference-compatible API, not only
-        through SequenceEncoder / SequenceDecoder), a frame never synchronises or allocates while another thread's
-        GraphCache.run is capturing.  The scope is re-entrant per thread."""
-        with CAPTURE_GUARD.frame():
+        """compress inside this model's frame scope (_ModelScope): while another thread's GraphCache.run is capturing, a frame
+        neither synchronises nor allocates (so two model INSTANCES may be driven from two host threads, through this
+        reference-compatible API as well as through SequenceEncoder / SequenceDecoder); a second thread entering the SAME
+        instance is refused.  The scope is re-entrant per thread."""
+        with self._frame():
             return self._compress_unguarded(x, qp, defer_stream=defer_stream)
 
     def _compress_unguarded(self, x, qp, defer_stream=False):
@@ -765,10 +811,11 @@ class DMC(CompressionModel):
         return {"bit_stream": bit_stream} if prev is None else {"bit_stream": bit_stream, "bit_stream_prev": prev}
 
     def decompress(self, bit_stream, sps, qp, defer_output=False):
-        """decompress under CAPTURE_GUARD.frame(): called directly from two host threads (the reference-compatible API, not only
-        through SequenceEncoder / SequenceDecoder), a frame never synchronises or allocates while another thread's
-        GraphCache.run is capturing.  The scope is re-entrant per thread."""
-        with CAPTURE_GUARD.frame():
+        """decompress inside this model's frame scope (_ModelScope): while another thread's GraphCache.run is capturing, a frame
+        neither synchronises nor allocates (so two model INSTANCES may be driven from two host threads, through this
+        reference-compatible API as well as through SequenceEncoder / SequenceDecoder); a second thread entering the SAME
+        instance is refused.  The scope is re-entrant per thread."""
+        with self._frame():
             return self._decompress_unguarded(bit_stream, sps, qp, defer_output=defer_output)
 
     def _decompress_unguarded(self, bit_stream, sps, qp, defer_output=False):
@@ -906,10 +953,11 @@ class DMCI(CompressionModel):
         return L.dcb_chain([n["sp_adaptor"][step]] + n["spatial"], y_hat, common, then_conv=n["spatial_out"])
 
     def compress(self, x, qp):
-        """compress under CAPTURE_GUARD.frame(): called directly from two host threads (the reference-compatible API, not only
-        through SequenceEncoder / SequenceDecoder), a frame never synchronises or allocates while another thread's
-        GraphCache.run is capturing.  The scope is re-entrant per thread."""
-        with CAPTURE_GUARD.frame():
+        """compress inside this model's frame scope (_ModelScope): while another thread's GraphCache.run is capturing, a frame
+        neither synchronises nor allocates (so two model INSTANCES may be driven from two host threads, through this
+        reference-compatible API as well as through SequenceEncoder / SequenceDecoder); a second thread entering the SAME
+        instance is refused.  The scope is re-entrant per thread."""
+        with self._frame():
             return self._compress_unguarded(x, qp)
 
     def _compress_unguarded(self, x, qp):
@@ -961,10 +1009,11 @@ class DMCI(CompressionModel):
         return {"bit_stream": bit_stream, "x_hat": x_hat}
 
     def decompress(self, bit_stream, sps, qp):
-        """decompress under CAPTURE_GUARD.frame(): called directly from two host threads (the reference-compatible API, not only
-        through SequenceEncoder / SequenceDecoder), a frame never synchronises or allocates while another thread's
-        GraphCache.run is capturing.  The scope is re-entrant per thread."""
-        with CAPTURE_GUARD.frame():
+        """decompress inside this model's frame scope (_ModelScope): while another thread's GraphCache.run is capturing, a frame
+        neither synchronises nor allocates (so two model INSTANCES may be driven from two host threads, through this
+        reference-compatible API as well as through SequenceEncoder / SequenceDecoder); a second thread entering the SAME
+        instance is refused.  The scope is re-entrant per thread."""
+        with self._frame():
             return self._decompress_unguarded(bit_stream, sps, qp)
 
     def _decompress_unguarded(self, bit_stream, sps, qp):

@@ -120,7 +120,10 @@ def test_rank_cpu_partition():
     # a cgroup CPU quota below the mask (the GPU boxes: 256 hardware threads visible, 16 CPUs granted): a rank keeps its
     # threads on its share of the quota inside its slice
     parts = [dist_utils.rank_cpus(r, 8, list(range(256)), gpu_cpus=[], quota=16) for r in range(8)]
-    assert all(len(p) == 2 for p in parts) and len({c for p in parts for c in p}) == 16
+    # (never fewer than MIN_RANK_CPUS: the quota limits CPU time, not parallelism - ADVICE round 3)
+    assert all(len(p) == dist_utils.MIN_RANK_CPUS for p in parts) and len({c for p in parts for c in p}) == 8 * dist_utils.MIN_RANK_CPUS
+    parts32 = [dist_utils.rank_cpus(r, 2, list(range(256)), gpu_cpus=[], quota=64) for r in range(2)]
+    assert all(len(p) == 32 for p in parts32)
     assert [p[0] for p in parts] == [32 * r for r in range(8)]
     assert dist_utils.cpus_granted(8, list(range(256)), quota=16) == 2 and dist_utils.cpus_granted(1, list(range(8)), quota=None) == 8
 

@@ -364,3 +364,60 @@ def test_pipeline_with_deferring_encoder_emits_every_packet(seqs):
         outs[defer] = (pkts, pics)
     assert len(outs[True][0]) == len(outs[False][0]) == n and outs[True][0] == outs[False][0]
     assert len(outs[True][1]) == n and all(np.array_equal(a, b) for a, b in zip(outs[True][1], outs[False][1]))
+
+
+@pytest.mark.parametrize("defer", [False, True])
+def test_returned_pictures_stay_valid_when_kept(defer):
+    """The reference returns a fresh x_hat per frame and its callers keep them (the harness computes a sequence's PSNR
+    afterwards): every picture handed out must still hold its own frame after later frames have been decoded.  (Round 3
+    wrote pictures into two alternating buffers: the third kept picture aliased the first - ADVICE round 3.)"""
+    from opendcvc_amd.pipeline import SequenceDecoder, SequenceEncoder
+    h, w, n = 96, 160, 7
+    dtype = torch.float16
+    frames = [torch.from_numpy(weights.synthetic_frame_yuv444(h, w, fi, 11)).to("cuda", dtype) for fi in range(n)]
+    ie, pe = hip_codecs(1234, 0.12, dtype)
+    idc, pdc = hip_codecs(1234, 0.12, dtype)
+    for m in (ie, pe, idc, pdc):
+        m.set_use_two_entropy_coders(False)
+    enc = SequenceEncoder(ie, pe, 28, intra_period=-1, reset_interval=32)
+    dec = SequenceDecoder(idc, pdc, h, w, False, defer_output=defer)
+    kept, copies = [], []
+    for x in frames:
+        r = dec.decode(enc.encode(x))
+        for t in (r if defer else [r]):
+            kept.append(t)                                  # the tensor itself ...
+            copies.append(t.float().cpu().numpy().copy())   # ... and its content at the time it was handed out
+    for t in dec.flush():
+        kept.append(t)
+        copies.append(t.float().cpu().numpy().copy())
+    assert len(kept) == n and len({t.data_ptr() for t in kept}) == n
+    for fi, (t, c) in enumerate(zip(kept, copies)):
+        assert np.array_equal(t.float().cpu().numpy(), c), f"picture {fi} was overwritten by a later frame"
+    assert not np.array_equal(copies[1], copies[3])
+
+
+def test_one_instance_refuses_a_second_thread():
+    """one model instance = one host thread at a time (its captured runs share scratch and the branch stream): a second
+    thread is refused with DcvcError instead of interleaving kernels on shared scratch"""
+    import threading
+    from opendcvc_amd._lib import DcvcError
+    _, p_net = hip_codecs(1234, 0.12, torch.float16)
+    seen = []
+
+    def intruder():
+        try:
+            with p_net._frame():
+                seen.append("entered")
+        except DcvcError as e:
+            seen.append(str(e))
+
+    with p_net._frame():
+        with p_net._frame():          # re-entrant for the owner
+            t = threading.Thread(target=intruder)
+            t.start()
+            t.join()
+    assert len(seen) == 1 and "one thread at a time" in seen[0]
+    t = threading.Thread(target=intruder)     # free again afterwards
+    t.start()
+    t.join()
+    assert seen[-1] == "entered"
