@@ -282,6 +282,10 @@ int64_t dcvc_rans_dec_get(dcvc_rans_dec*, int8_t* out, int64_t capacity);
  * calling thread, the second on its worker. */
 int dcvc_rans_dec_decode_and_get_y(dcvc_rans_dec*, const uint8_t* indexes, int64_t n, int group,
                                    int8_t* out);
+/* Integrity check after the LAST symbol of a frame has been decoded (no reference counterpart: the reference decodes a
+ * corrupt or truncated payload into garbage, rans.cpp:356-429): a rANS decoder that has undone every encoder step is back
+ * in the encoder's initial state and has consumed every byte; returns 0, or -4 with dcvc_last_error() set. */
+int dcvc_rans_dec_check_end(dcvc_rans_dec*);
 /* pmf_to_quantized_cdf (py_rans.cpp:307-364); out holds n+1 entries */
 int dcvc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, uint32_t* out);
 

@@ -105,6 +105,7 @@ _SIGS = {
     "dcvc_rans_dec_decode_z": (_I, [_P, _L, _I, _I, _I]),
     "dcvc_rans_dec_get": (_L, [_P, _P, _L]),
     "dcvc_rans_dec_decode_and_get_y": (_I, [_P, _P, _L, _I, _P]),
+    "dcvc_rans_dec_check_end": (_I, [_P]),
     "dcvc_pmf_to_quantized_cdf": (_I, [_P, _I, _I, _P]),
     "dcvc_host_alloc": (_P, [c_size_t]),
     "dcvc_host_free": (None, [_P]),

@@ -1,29 +1,8 @@
-// api.cpp - error state, device discovery, pinned host memory and stream-ordered copies of the
-// C ABI (include/dcvc_amd.h).
-#include <cstdarg>
-#include <cstdio>
-
+// api.cpp - device discovery, pinned host memory and stream-ordered copies of the C ABI
+// (include/dcvc_amd.h).  The error state lives in error.cpp (host-only: also part of the sanitizer build).
 #include "common.hpp"
 
-namespace dcvc {
-
-static thread_local char g_err[512] = "";
-
-void set_error(const char* fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-}
-
-}  // namespace dcvc
-
 extern "C" {
-
-int dcvc_abi_version(void) { return DCVC_ABI_VERSION; }
-
-const char* dcvc_last_error(void) { return dcvc::g_err; }
 
 int dcvc_device_count(void)
 {

@@ -482,18 +482,17 @@ struct DecCursor {
         }
         int32_t value = (int32_t)s;
         if (s == t.max_value) {               // escape: Exp-Golomb-like bypass bits follow
-            int32_t val = (int32_t)get_bits();
-            int32_t n_bypass = val;
-            while (val == kBypassMax && !overrun) {
-                val = (int32_t)get_bits();
-                n_bypass += val;
+            // (a valid stream carries at most 16 groups - 32 bits - per escape; a corrupt one may claim any number: the
+            // count saturates, the value is assembled without signed overflow, and the decoder keeps its position rules)
+            uint32_t val = get_bits();
+            uint32_t n_bypass = val;
+            while (val == (uint32_t)kBypassMax && !overrun) {
+                val = get_bits();
+                n_bypass = n_bypass < 1024u ? n_bypass + val : n_bypass;
             }
-            int32_t raw = 0;
-            for (int j = 0; j < n_bypass && j < 16; ++j) {
-                val = (int32_t)get_bits();
-                raw |= val << (j * kBypassBits);
-            }
-            value = raw >> 1;
+            uint32_t raw = 0;
+            for (uint32_t j = 0; j < n_bypass && j < 16; ++j) raw |= get_bits() << (j * kBypassBits);
+            value = (int32_t)(raw >> 1);
             if (raw & 1)
                 value = -value - 1;
             else
@@ -508,8 +507,10 @@ struct DecHalf {
     size_t pos = 0;
     uint32_t state = 0;
     bool overrun = false;
+    int64_t decoded = 0;               // symbols decoded since init()
     void init(const uint8_t* s, size_t n, bool reversed)
     {
+        decoded = 0;
         buf.assign(n + 16, 0);
         if (reversed)
             std::reverse_copy(s, s + n, buf.begin());
@@ -536,6 +537,7 @@ struct DecHalf {
         DecCursor c = open();
         for (int64_t c0 = a; c0 < b; c0 += 32) {
             uint32_t m = kept_mask32_u8(idx + c0, b - c0);
+            decoded += __builtin_popcount(m);
             while (m) {
                 const int bit = __builtin_ctz(m);
                 m &= m - 1;
@@ -554,6 +556,7 @@ struct DecHalf {
             const int64_t stop = std::min<int64_t>(cnt, i + per_channel);
             for (; i < stop; ++i) out[i] = (int8_t)c.decode(*tab);
         }
+        decoded += cnt;
         close(c);
     }
 };
@@ -861,6 +864,42 @@ int64_t dcvc_rans_dec_get(dcvc_rans_dec* d, int8_t* out, int64_t capacity)
     }
     std::memcpy(out, d->out.data(), d->out.size());
     return (int64_t)d->out.size();
+}
+
+int dcvc_rans_dec_check_end(dcvc_rans_dec* d)
+{
+    DCVC_REQUIRE(d, "dcvc_rans_dec_check_end: null coder");
+    d->worker[0].wait_idle();
+    d->worker[1].wait_idle();
+    const int halves = d->two ? 2 : 1;
+    int64_t consumed = 0, used = 0;
+    for (int h = 0; h < halves; ++h) {
+        const DecHalf& c = d->half[h];
+        if (c.buf.size() < 16) continue;                     // set_stream() not called
+        if (c.overrun) {
+            dcvc::set_error("dcvc_rans_dec_check_end: bit stream exhausted (corrupt or truncated stream)");
+            return dcvc::E_STREAM;
+        }
+        if (c.decoded == 0) continue;                        // an empty half has no stream of its own
+        // decoding undoes the encoder step by step: after the last symbol the state is the encoder's initial one
+        if (c.state != kRansL) {
+            dcvc::set_error("dcvc_rans_dec_check_end: coder %d does not end in its initial state (corrupt or truncated "
+                            "stream, or not every symbol of the frame has been decoded)", h);
+            return dcvc::E_STREAM;
+        }
+        consumed += (int64_t)c.pos;
+        ++used;
+    }
+    if (used == halves) {
+        // every byte belongs to a coder: the two halves share at most 8 bytes (merge rule of get_encoded_stream)
+        const int64_t n = (int64_t)d->half[0].buf.size() - 16;
+        if (consumed < n || consumed > n + (d->two ? 8 : 0)) {
+            dcvc::set_error("dcvc_rans_dec_check_end: %lld of %lld stream bytes consumed (trailing or missing bytes)",
+                            (long long)consumed, (long long)n);
+            return dcvc::E_STREAM;
+        }
+    }
+    return 0;
 }
 
 int dcvc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, uint32_t* out)

@@ -214,6 +214,11 @@ class EntropyCoder:
         n = check(_lib.lib().dcvc_rans_dec_get(self.dec, _ip(out), out.size), "get_decoded")
         return n
 
+    def check_end(self):
+        """After the last symbol of a frame: raises DcvcError if the payload was corrupt or truncated (the coder is not
+        back in its initial state / has bytes left over).  No reference counterpart (it decodes garbage silently)."""
+        check(_lib.lib().dcvc_rans_dec_check_end(self.dec), "corrupt or truncated frame payload")
+
     def decode_and_get_y(self, indexes, cdf_group_index, out):
         """Synchronous: decodes straight from `indexes` into `out` (both host arrays of the same length)."""
         if indexes.dtype != np.uint8 or out.dtype != np.int8 or out.size < indexes.size or \

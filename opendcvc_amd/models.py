@@ -875,6 +875,7 @@ class DMC(CompressionModel):
         self._pending_half(1)
         ev.synchronize()
         sym1 = self._decode_on_host(idx1, n_half, "p1")
+        ec.check_end()                    # corrupt / truncated payload: DcvcError here, not a garbage picture
 
         def after_step1():
             # runs must be idempotent on buffers they did not allocate (see GraphCache): the second half is
@@ -1051,6 +1052,8 @@ class DMCI(CompressionModel):
             ev.record()
             ev.synchronize()                       # the index copy of this step has landed
             sym = self._decode_on_host(idx, nsym, f"i{step}")
+            if step == 3:
+                ec.check_end()            # corrupt / truncated payload: DcvcError here, not a garbage picture
 
             def after(step=step, sym=sym, means=means, y_prev=y_prev):
                 y_new = torch.empty((yh, yw, C), dtype=dtype, device=device)

@@ -421,3 +421,38 @@ def test_one_instance_refuses_a_second_thread():
     t.start()
     t.join()
     assert seen[-1] == "entered"
+
+
+def test_damaged_payload_raises_instead_of_decoding_garbage():
+    """DMCI / DMC.decompress check the coder's end state after the frame's last symbol (dcvc_rans_dec_check_end): a
+    truncated or bit-flipped payload raises DcvcError; the models stay usable (the reference decodes garbage,
+    rans.cpp:356-429)."""
+    from opendcvc_amd._lib import DcvcError
+    h, w = 96, 160
+    dtype = torch.float16
+    frames = [torch.from_numpy(weights.synthetic_frame_yuv444(h, w, fi, 5)).to("cuda", dtype) for fi in range(2)]
+    ie, pe = hip_codecs(1234, 0.12, dtype)
+    idc, pdc = hip_codecs(1234, 0.12, dtype)
+    for m in (ie, pe, idc, pdc):
+        m.set_use_two_entropy_coders(False)
+    sps = dict(height=h, width=w, ec_part=0, use_ada_i=0)
+    ei = ie.compress(frames[0], 30)
+    pe.clear_dpb()
+    pe.add_ref_frame(None, ei["x_hat"])
+    ep = pe.compress(frames[1], 30)
+    for bits in (ei["bit_stream"][:-3], ei["bit_stream"][:len(ei["bit_stream"]) // 2], ei["bit_stream"] + b"\x01"):
+        with pytest.raises(DcvcError):
+            idc.decompress(bits, sps, 30)
+    di = idc.decompress(ei["bit_stream"], sps, 30)
+    assert torch.equal(di["x_hat"], ei["x_hat"])
+    flipped = bytearray(ep["bit_stream"])
+    flipped[7] ^= 0x10
+    for bits in (ep["bit_stream"][:-2], bytes(flipped)):
+        pdc.clear_dpb()
+        pdc.add_ref_frame(None, di["x_hat"])
+        with pytest.raises(DcvcError):
+            pdc.decompress(bits, sps, 30)
+    pdc.clear_dpb()
+    pdc.add_ref_frame(None, di["x_hat"])
+    dp = pdc.decompress(ep["bit_stream"], sps, 30)
+    assert torch.equal(pdc.dpb[0].feature, pe.dpb[0].feature) and dp["x_hat"] is not None
