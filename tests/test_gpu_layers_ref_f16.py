@@ -1,0 +1,108 @@
+"""fp16 HIP kernels against the REFERENCE's own fp16 run, layer by layer.
+
+tests/golden/ops_small_f16.npz holds what the reference's DepthConvBlock / SubpelConv2x / nn.Conv2d produce in .half()
+(forward_torch, src/layers/layers.py:44-51,92-106: every conv output and every activation rounded to fp16 - the arithmetic of
+the reference's fp16 GPU path, src/layers/extensions/inference/impl.cpp:53-121) on seeded weights and inputs
+(tests/golden/make_golden_f16.py).  The HIP kernels deviate from that arithmetic on purpose (weights of the
+gated convs pre-scaled by -4 log2 e before their fp16 rounding, bias seeded into the fp32 accumulator, NO fp16 rounding
+between a conv and its activation, between the depthwise conv and W2, ...): they round less often.  This pins the
+deviation per layer instead of only end to end (2 % bytes / 0.05 dB):
+
+  * HIP fp16 vs reference fp16:  max |d| <= REF_MAX_RMS x rms,  mean |d| <= REF_MEAN_RMS x rms   (measured bounds below)
+  * against the fp32 value both approximate (fp32 oracle on the same fp16-rounded weights and input), the HIP result is
+    not further away than the reference's own fp16 result (mean |d|, 10 % slack).
+The measured figures are written to gpurun_out/f16_vs_ref.json (committed as profiles/r04_f16_vs_ref.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dcvc_oracle as O
+from layer_utils import F16_CONV_CASES, F16_DCB_CASES, F16_LARGE_KEEP, f16_conv_inputs, f16_dcb_inputs
+
+pytestmark = pytest.mark.gpu
+
+# measured on MI355X (profiles/r04_f16_vs_ref.json): blocks max 5.3e-3 .. 9.7e-3 x rms, mean 3.3e-4 .. 4.3e-4; convs
+# max <= 2.0e-3, mean <= 1.1e-4.  One fp16 ulp of a value of 4 - 8 rms is 2 - 4e-3 x rms: the maxima are 2 - 3 ulps of the
+# largest outputs, i.e. the two implementations' own rounding errors (each ~1.5 ulp, table above) side by side.
+REF_MAX_RMS = 1.6e-2
+REF_MEAN_RMS = 6e-4
+STATS = {}
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops_small_f16.npz"))
+
+
+def _rh(a):
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+def _to_dev(x_nchw, cp):
+    _, C, H, W = x_nchw.shape
+    t = torch.zeros((H, W, cp), dtype=torch.float16, device="cuda")
+    t[:, :, :C] = torch.from_numpy(np.ascontiguousarray(x_nchw[0].transpose(1, 2, 0)))
+    return t
+
+
+def _check(name, got, ref16, truth):
+    """got / ref16 / truth: [H, W, C] float32 (HIP fp16, reference fp16, fp32 value)"""
+    rms = float(np.sqrt(np.mean(truth.astype(np.float64) ** 2))) + 1e-9
+    d_ref = np.abs(got.astype(np.float64) - ref16)
+    e_hip = np.abs(got.astype(np.float64) - truth)
+    e_ref = np.abs(ref16.astype(np.float64) - truth)
+    STATS[name] = dict(rms=rms, hip_vs_ref_max=float(d_ref.max()) / rms, hip_vs_ref_mean=float(d_ref.mean()) / rms,
+                       hip_vs_fp32_max=float(e_hip.max()) / rms, hip_vs_fp32_mean=float(e_hip.mean()) / rms,
+                       ref_vs_fp32_max=float(e_ref.max()) / rms, ref_vs_fp32_mean=float(e_ref.mean()) / rms,
+                       identical_fraction=float(np.mean(got == ref16)))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(STATS, open(os.path.join(out, "f16_vs_ref.json"), "w"), indent=1)
+    assert d_ref.max() <= REF_MAX_RMS * rms, f"{name}: max |HIP - reference fp16| = {d_ref.max() / rms:.2e} x rms"
+    assert d_ref.mean() <= REF_MEAN_RMS * rms, f"{name}: mean |HIP - reference fp16| = {d_ref.mean() / rms:.2e} x rms"
+    assert e_hip.mean() <= 1.10 * e_ref.mean() + 1e-7, \
+        f"{name}: HIP fp16 is further from fp32 ({e_hip.mean() / rms:.2e}) than the reference's fp16 ({e_ref.mean() / rms:.2e})"
+
+
+@pytest.mark.parametrize("case", F16_DCB_CASES, ids=[c[0] for c in F16_DCB_CASES])
+def test_depth_conv_block_f16_vs_reference_half(gold, case):
+    from opendcvc_amd import nn
+    name, cin, c, adaptor, shortcut, quant, H, W, seed = case
+    sd, x, q = f16_dcb_inputs(case)
+    ref16 = gold[name + ".y16"][0].astype(np.float32).transpose(1, 2, 0)
+    keep = ref16.shape[2]
+    assert keep == (F16_LARGE_KEEP if H * W >= 12000 else c)
+    sd16 = {k: _rh(v) for k, v in sd.items()}
+    truth = O.Net(sd16).dcb(np.ascontiguousarray(x[0].astype(np.float32).transpose(1, 2, 0)), "m", shortcut=shortcut, q=q)
+    blk = nn.DepthConvBlock(sd, "m", torch.float16, shortcut=shortcut)
+    out = blk(_to_dev(x, blk.cin_p), quant=None if q is None else torch.from_numpy(q).cuda())
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    assert not np.any(got[:, :, c:])
+    _check(name, got[:, :, :keep], ref16, truth[:, :, :keep])
+
+
+@pytest.mark.parametrize("case", F16_CONV_CASES, ids=[c[0] for c in F16_CONV_CASES])
+def test_conv_f16_vs_reference_half(gold, case):
+    from opendcvc_amd import _lib, nn
+    name, kind, cin, cout, k, H, W, seed = case
+    sd, x = f16_conv_inputs(case)
+    ref16 = gold[name + ".y16"][0].astype(np.float32).transpose(1, 2, 0)
+    sd16 = {kk: _rh(v) for kk, v in sd.items()}
+    xh = np.ascontiguousarray(x[0].astype(np.float32).transpose(1, 2, 0))
+    if kind == "subpel":
+        truth = O.Net(sd16).subpel(xh, "m", k // 2)
+        layer = nn.SubpelConv2x(sd, "m", torch.float16, k // 2)
+        out = layer(_to_dev(x, layer.conv.cin_p))
+    else:
+        stride, pad = (2, 1 if k == 3 else 0) if kind == "s2" else (1, 0)
+        truth = O.Net(sd16).conv(xh, "m", stride, pad)
+        layer = nn.Conv2d(sd, "m", torch.float16, stride, pad, _lib.EPI_BIAS)
+        out = layer(_to_dev(x, layer.cin_p))
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    assert got.shape[:2] == ref16.shape[:2] and not np.any(got[:, :, cout:])
+    _check(name, got[:, :, :cout], ref16, truth)
