@@ -141,6 +141,7 @@ class _ModelScope:
 
 # DCVC_NO_FORK=1: no second stream inside a run (the temporal prior encoder then runs behind the hyper decoder)
 _FORK = os.environ.get("DCVC_NO_FORK") != "1"
+_PICTURE_RING = os.environ.get("DCVC_PICTURE_RING") == "1"
 
 
 class GraphCache:
@@ -348,7 +349,14 @@ class CompressionModel(tnn.Module):
         """PixelShuffle(8) + clamp of the last conv's output into a FRESH tensor, launched outside the captured run (whose own
         output buffer is overwritten by the next frame).  The reference returns a fresh tensor per frame and callers keep
         them (a sequence's pictures for the PSNR, the DPB): no ring of picture buffers - the kernel writes the new tensor
-        directly, so there is no copy either, and the allocator hands the block back once the caller drops the picture."""
+        directly, so there is no copy either, and the allocator hands the block back once the caller drops the picture.
+        (DCVC_PICTURE_RING=1, a developer switch for A/B timing only: round 3's two alternating buffers - a picture is
+        then overwritten by the second following frame.)"""
+        if _PICTURE_RING:
+            H, W, _, _ = L._geom(head)
+            self._pic_parity = getattr(self, "_pic_parity", 0) ^ 1
+            buf = self._buffer(f"picture_{self._pic_parity}", (1, 3, H * 8, W * 8), head.dtype, head.device)
+            return self._shuffle8_clamp(head, out=buf)
         return self._shuffle8_clamp(head)
 
     def _thres(self):
