@@ -595,6 +595,8 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
 #ifdef DCVC_DIAG
     if (p.stamps && tid == 0) {
         unsigned long long* o = p.stamps + (size_t)blockIdx.x * 16;
+#pragma unroll
+        for (int k = nslab + 1; k <= 4; ++k) td[k] = td[nslab < 4 ? nslab : 4];   // stamps of slabs this width does not have
         o[0] = ts1 - ts0;   // loads + depthwise
         o[1] = ts2 - ts1;   // GEMM2
         o[2] = ts3 - ts2;   // (+b2) store, o pass

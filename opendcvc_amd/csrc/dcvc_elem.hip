@@ -285,11 +285,14 @@ __global__ void round_z_kernel(T* z, int64_t ldz, int64_t HW, int C, int8_t* z_c
 template <typename T>
 __global__ void z_from_int8_kernel(const int8_t* z_chw, int64_t HW, int C, T* out, int64_t ldo)
 {
+    // consecutive threads read consecutive bytes of the CHW symbol array: it may live in pinned HOST memory (the decoder
+    // hands the coder's output over without a copy command), where a strided byte read is a bus transaction each; the
+    // scattered 2 / 4-byte writes go to device memory (65 K elements at 1080p)
     const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
     if (i >= HW * C) return;
-    const int c = (int)(i % C);
-    const int64_t p = i / C;
-    st(out, p * ldo + c, (float)z_chw[(int64_t)c * HW + p]);
+    const int c = (int)(i / HW);
+    const int64_t p = i - (int64_t)c * HW;
+    st(out, p * ldo + c, (float)z_chw[i]);
 }
 
 // ------------------------------------------------------------------ checkerboard prior loop
@@ -397,6 +400,14 @@ __global__ __launch_bounds__(EB) void prior_dec_index_kernel(int n_groups, int s
         sp[cc * PT + pl] = keep ? dcvc_scale_to_index(scl, kScaleMin, kScaleMax, kLogScaleMin, kLogStepRecip) : (uint8_t)0xFF;
     }
     __syncthreads();
+    // The index array may live in pinned HOST memory (read in place by the host coder: no copy command).  A channel's PT = 16
+    // pixels of this block are 16 contiguous bytes of the CHW array: one 16-byte store per channel where the rows are
+    // aligned (H W a multiple of 16: 1080p, 4K), byte stores otherwise.
+    if ((HW & (PT - 1)) == 0 && (reinterpret_cast<uintptr_t>(idx_chw) & 15) == 0) {
+        for (int cc = threadIdx.x; cc < Cg; cc += EB)
+            *reinterpret_cast<uint4*>(idx_chw + (int64_t)cc * HW + p0) = *reinterpret_cast<const uint4*>(sp + cc * PT);
+        return;
+    }
     for (int it = threadIdx.x; it < PT * Cg; it += EB) {
         const int cc = it / PT, pl = it - cc * PT;
         const int64_t p = p0 + pl;
@@ -414,10 +425,16 @@ __global__ __launch_bounds__(EB) void prior_dec_restore_kernel(int n_groups, int
     const int Cg = C / n_groups;
     const int64_t HW = (int64_t)H * W;
     const int64_t p0 = (int64_t)blockIdx.x * PT;
-    for (int it = threadIdx.x; it < PT * Cg; it += EB) {
-        const int cc = it / PT, pl = it - cc * PT;
-        const int64_t p = p0 + pl;
-        sp[cc * PT + pl] = p < HW ? sym_chw[(int64_t)cc * HW + p] : (int8_t)0;
+    // (the symbols may live in pinned HOST memory, written there by the host coder: 16-byte loads where the rows are aligned)
+    if ((HW & (PT - 1)) == 0 && (reinterpret_cast<uintptr_t>(sym_chw) & 15) == 0) {
+        for (int cc = threadIdx.x; cc < Cg; cc += EB)
+            *reinterpret_cast<uint4*>(sp + cc * PT) = *reinterpret_cast<const uint4*>(sym_chw + (int64_t)cc * HW + p0);
+    } else {
+        for (int it = threadIdx.x; it < PT * Cg; it += EB) {
+            const int cc = it / PT, pl = it - cc * PT;
+            const int64_t p = p0 + pl;
+            sp[cc * PT + pl] = p < HW ? sym_chw[(int64_t)cc * HW + p] : (int8_t)0;
+        }
     }
     __syncthreads();
     for (int it = threadIdx.x; it < PT * Cg; it += EB) {

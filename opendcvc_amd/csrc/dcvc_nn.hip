@@ -1150,8 +1150,9 @@ int launch_tail128(const TailParams& tp, int H, int W, hipStream_t st)
         if (printed++ % 16 == 15) {
             const char* names[15] = {"loads+dw", "gemm2", "o_pass", "u0", "ffn", "r+store", "", "", "dw:issue+stage0", "barrier0", "slab0", "slab1", "slab2", "slab3", "fused"};
             fprintf(stderr, "[t128 stamps C=%d tile=%d grid=%d]", C, t128::Geo<G>::M, grid);
+            constexpr int nslab = C / G::DW_SLAB;      // the kernel stamps min(nslab, 4) slabs: print only those
             for (int k = 0; k < 15; ++k) {
-                if (k == 6 || k == 7) continue;
+                if (k == 6 || k == 7 || (k >= 10 && k <= 13 && k - 10 >= nslab)) continue;
                 std::vector<unsigned long long> v(grid);
                 for (int b = 0; b < grid; ++b) v[b] = hs[(size_t)b * 16 + k];
                 std::sort(v.begin(), v.end());

@@ -410,20 +410,15 @@ class CompressionModel(tnn.Module):
         check(_lib.lib().dcvc_round_z(L.dtype_code(z.dtype), L._p(z), ld, H, W, C, L._p(z8), self._stream()), "round_z")
         return z, z8
 
-    def _z_to_device(self, z_host, zh, zw, dtype, device):
-        z8 = torch.empty(self.z_channel * zh * zw, dtype=torch.int8, device=device)
-        check(_lib.lib().dcvc_memcpy_h2d(L._p(z8), z_host.ctypes.data_as(ctypes.c_void_p), z8.numel(), self._stream()), "h2d")
+    def _z_to_device(self, z_pinned, zh, zw, dtype, device):
+        """decoded z symbols (int8, CHW, in a PINNED host buffer) -> z_hat on the device: the kernel reads the pinned
+        buffer in place (coalesced byte reads over the host link; no copy command)"""
         out = torch.empty((zh, zw, self.z_channel), dtype=dtype, device=device)
-        check(_lib.lib().dcvc_z_from_int8(L.dtype_code(dtype), L._p(z8), zh, zw, self.z_channel, L._p(out),
-                                          self.z_channel, self._stream()), "z_from_int8")
+        check(_lib.lib().dcvc_z_from_int8(L.dtype_code(dtype), ctypes.c_void_p(z_pinned.dptr), zh, zw, self.z_channel,
+                                          L._p(out), self.z_channel, self._stream()), "z_from_int8")
         return out
 
     # ---- host <-> device staging
-    def _d2h(self, key, t):
-        buf = self.entropy_coder.pinned(key, t.numel() * t.element_size())
-        check(_lib.lib().dcvc_memcpy_d2h(ctypes.c_void_p(buf.ptr), L._p(t), t.numel() * t.element_size(), self._stream()), "d2h")
-        return buf
-
     def _symbols_to_host(self, key, z8, packed):
         """Encoder hand-off without a copy command: z (int8) and the KEPT y symbols of each part of `packed`, compacted in
         order on the device, are written by kernels straight into pinned host buffers (dcvc_compact_symbols).  Returns
@@ -451,18 +446,6 @@ class CompressionModel(tnn.Module):
             scales.stride(1), L._p(means), means.stride(1), H, W, C, self._thres(), L._p(yhat), yhat.stride(1),
             L._p(yhat), yhat.stride(1), L._p(packed), self._stream()), "prior_enc_step")
 
-    def _prior_dec_index(self, groups, step, scales, H, W, C, idx):
-        check(_lib.lib().dcvc_prior_dec_index(L.dtype_code(scales.dtype), groups, step, L._p(scales), scales.stride(1),
-                                              H, W, C, self._thres(), L._p(idx), self._stream()), "prior_dec_index")
-
-    def _prior_dec_restore(self, groups, step, sym, means, yhat, H, W, C, out=None):
-        """y_hat += this step's symbols + means at the step's positions (step 0: plain write of every position);
-        in place unless `out` is given."""
-        out = yhat if out is None else out
-        check(_lib.lib().dcvc_prior_dec_restore(L.dtype_code(means.dtype), groups, step, L._p(sym), L._p(means),
-                                                means.stride(1), H, W, C, L._p(yhat), yhat.stride(1), L._p(out),
-                                                out.stride(1), self._stream()), "prior_dec_restore")
-
     def _prior_finish(self, q_mode, yhat, qsrc):
         H, W, C, ld = L._geom(yhat)
         check(_lib.lib().dcvc_prior_finish(L.dtype_code(yhat.dtype), q_mode, L._p(yhat), ld, L._p(qsrc), qsrc.stride(1),
@@ -471,11 +454,18 @@ class CompressionModel(tnn.Module):
     # one checkerboard decoding step = three pieces, so that the device pieces can sit inside captured runs
     # (device index build -> host rANS decode -> device restore)
     def _index_to_host(self, groups, step, scales, H, W, C, key):
-        """device: cdf indexes of the step's symbols -> pinned host buffer (stream-ordered copy)"""
+        """device: cdf indexes of the step's symbols -> pinned host buffer (stream-ordered copy).
+        Measured in round 4 (profiles/r04_dec_inplace.txt): the kernel writing the indexes straight into the pinned buffer takes
+        39 us instead of 5.4 us + a ~10 us copy command, and the restore kernel reading the symbols in place 108 us instead
+        of 7.7 us + copy - a channel's run of 16 pixels is 16 bytes, one bus transaction per lane, where the copy moves
+        whole lines; only z (read coalesced, 65 KB) is taken in place."""
         n = (C // groups) * H * W
         idx = torch.empty(n, dtype=torch.uint8, device=scales.device)
-        self._prior_dec_index(groups, step, scales, H, W, C, idx)
-        return self._d2h(key + "_idx", idx)
+        check(_lib.lib().dcvc_prior_dec_index(L.dtype_code(scales.dtype), groups, step, L._p(scales), scales.stride(1),
+                                              H, W, C, self._thres(), L._p(idx), self._stream()), "prior_dec_index")
+        buf = self.entropy_coder.pinned(key + "_idx", n)
+        check(_lib.lib().dcvc_memcpy_d2h(ctypes.c_void_p(buf.ptr), L._p(idx), n, self._stream()), "d2h")
+        return buf
 
     def _decode_on_host(self, idx_host, n, key):
         """host: rANS-decode n symbols (the caller has waited for the index copy)"""
@@ -484,10 +474,14 @@ class CompressionModel(tnn.Module):
         return sb
 
     def _symbols_to_device(self, sym_host, n, groups, step, means, yhat, H, W, C, out=None):
-        """device: upload the decoded symbols and restore y_hat at the step's positions"""
+        """device: upload the decoded symbols (stream-ordered copy, see _index_to_host) and restore y_hat at the step's
+        positions"""
+        out = yhat if out is None else out
         sym = torch.empty(n, dtype=torch.int8, device=yhat.device)
         check(_lib.lib().dcvc_memcpy_h2d(L._p(sym), ctypes.c_void_p(sym_host.ptr), n, self._stream()), "h2d")
-        self._prior_dec_restore(groups, step, sym, means, yhat, H, W, C, out=out)
+        check(_lib.lib().dcvc_prior_dec_restore(L.dtype_code(means.dtype), groups, step, L._p(sym), L._p(means),
+                                                means.stride(1), H, W, C, L._p(yhat), yhat.stride(1), L._p(out),
+                                                out.stride(1), self._stream()), "prior_dec_restore")
 
 
 # =============================================================================== DMC (P frames)
@@ -859,7 +853,7 @@ class DMC(CompressionModel):
         ec.get_decoded(zb.view(np.int8, nz))
 
         def after_z():
-            z_hat = self._z_to_device(zb.view(np.int8, nz), zh, zw, dtype, device)
+            z_hat = self._z_to_device(zb, zh, zw, dtype, device)
             params = self._prior_params(z_hat, x1, q["q_feature"], yh, yw)
             y_hat = torch.empty((yh, yw, C), dtype=dtype, device=device)
             return params, y_hat, self._index_to_host(2, 0, params[:, :, C:2 * C], yh, yw, C, "p0")
@@ -1047,7 +1041,7 @@ class DMCI(CompressionModel):
         ec.get_decoded(zb.view(np.int8, nz))
 
         def first():
-            z_hat = self._z_to_device(zb.view(np.int8, nz), zh, zw, dtype, device)
+            z_hat = self._z_to_device(zb, zh, zw, dtype, device)
             params = self._prior_params(z_hat, yh, yw)
             common = n["reduction"](params)
             return params, common, self._index_to_host(4, 0, params[:, :, 2:2 + C], yh, yw, C, "i0")
