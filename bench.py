@@ -369,6 +369,10 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     dtype = torch.float16
     torch.set_grad_enabled(False)
+    # no intra-op thread pool (the reference harness does the same, src/utils/common.py:23): its idle workers compete with
+    # the two pipeline threads and the rANS workers for the granted cores - three runs each on one box, --steps 20:
+    # 377 / 331 / 351 frames/s with the pool, 377 / 380 / 380 without (profiles/r04_host_threads_ab.txt)
+    torch.set_num_threads(1)
 
     (ie, pe), (idec, pdec) = load_models(dtype, device, world, rank)
     two = use_two_entropy_coders(HEIGHT, WIDTH)

@@ -200,11 +200,20 @@ class EncodeDecodePipeline:
                 while q.get() is not None:                  # keep the encoder from blocking on a full queue
                     pass
 
+        # The two stage threads share the interpreter lock: with the default 5 ms switch interval a stage that becomes
+        # runnable (its GPU event fired, its packet arrived) may wait that long for the other stage's Python code; 0.2 ms
+        # for the duration of the run (steadier frame times: profiles/r04_host_threads_ab.txt)
+        import sys
+        old_interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(old_interval, 2e-4))
         threads = [threading.Thread(target=enc_stage), threading.Thread(target=dec_stage)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        try:
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            sys.setswitchinterval(old_interval)
         if errors:
             raise errors[0]
 
