@@ -463,6 +463,15 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
     // [W3 x o -> u(j+1)] (G3: KS k-steps of one fragment) as a sequence of slots = one MFMA + what is issued in its shadow:
     // one LDS read of the next k-step's pixel fragments, the ring refill after a fragment's last MFMA, and (GATE) the gate
     // pieces of chunk j.  OFF: ring slot of the step's first fragment; jb: chunk whose bias is requested.
+    auto wload_ffn = [&]() __attribute__((always_inline)) {
+#ifdef DCVC_DIAG
+        if (p.ablate & 256) {                       // timing experiment: the FFN re-reads the same fragment (one L1 line set)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, 0, 0));
+        }
+#endif
+        return wload();
+    };
     auto step = [&](auto G4c, auto G3c, auto GATEc, auto OFFc, const floatx16 (&ug)[PTW], floatx16 (&un)[PTW], half_t* vcur,
                     const half_t* vprev, int jb) __attribute__((always_inline)) {
         constexpr bool G4 = decltype(G4c)::value, G3 = decltype(G3c)::value, GATE = decltype(GATEc)::value;
@@ -471,6 +480,9 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
         constexpr int TM = N4 * NTW * PTW + (G3 ? KS * PTW : 0);       // MFMAs (slots) of the step
         constexpr int PPS = GATE ? (NPIECE + TM - 1) / TM : 0;          // gate pieces per slot
         auto load_b1 = [&](int idx, int t) __attribute__((always_inline)) {
+#ifdef DCVC_DIAG
+            if (p.ablate & 512) idx = idx < N4 ? 0 : N4;      // timing experiment: every k-step reads the same LDS fragment
+#endif
             if (idx < N4) return *reinterpret_cast<const half8*>(vprev + (prow + 32 * t) * LDV + 8 * hh + idx * 16);
             return bfrag_x(t, idx - N4);
         };
@@ -490,11 +502,11 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
                     if (idx < N4) {
                         const int i = q / PTW, k = (OFF + idx * NTW + i) % D;
                         acc[i][t] = mfma32(ring[k], bc[t], acc[i][t]);
-                        if (t == PTW - 1) ring[k] = wload();
+                        if (t == PTW - 1) ring[k] = wload_ffn();
                     } else {
                         const int k = (OFF + N4 * NTW + (idx - N4)) % D;
                         un[t] = mfma32(ring[k], bc[t], idx == N4 ? biasv : un[t]);   // (first k-step: starts at the bias)
-                        if (t == PTW - 1) ring[k] = wload();
+                        if (t == PTW - 1) ring[k] = wload_ffn();
                         if (idx == N4 && t == PTW - 1) bias_load(jb);                // the next chunk's, into the same registers
                     }
                     if constexpr (GATE) {
@@ -512,6 +524,9 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
 #pragma unroll
             for (int t = 0; t < PTW; ++t) bc[t] = bn[t];
         }
+#ifdef DCVC_DIAG
+        if (p.ablate & 128) return;                 // timing experiment: no barrier between the chunks (wrong results)
+#endif
         if constexpr (GATE) __syncthreads();
     };
     using T_ = std::true_type;
