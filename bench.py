@@ -61,7 +61,7 @@ BASELINE_ENC_FPS, BASELINE_DEC_FPS = 125.2, 112.8
 WEIGHTS_VIA = {"how": "generated in process"}
 
 
-def load_models(dtype, device, world, rank):
+def load_models(dtype, device, world, rank, coll_device=None):
     """Rank 0 generates the weights, every other rank receives them in ONE RCCL broadcast per model (the only
     collective of the path, BASELINE.json north_star).  Should the broadcast itself fail on a node (a fabric / RCCL
     problem, not a codec one) the ranks fall back to generating the same deterministic weights themselves and the line
@@ -71,8 +71,8 @@ def load_models(dtype, device, world, rank):
         sd = weights.make_state_dict(name, 1234) if rank == 0 else None
         if world > 1 and WEIGHTS_VIA["how"] != "generated per rank":
             try:
-                sd = dist_utils.broadcast_state_dict(name, sd, device, rank, world)   # one RCCL broadcast per model
-                WEIGHTS_VIA["how"] = "rccl broadcast from rank 0"
+                sd = dist_utils.broadcast_state_dict(name, sd, coll_device or device, rank, world)   # one RCCL broadcast per model
+                WEIGHTS_VIA["how"] = ("rccl" if torch.distributed.get_backend() == "nccl" else torch.distributed.get_backend()) + " broadcast from rank 0"
             except Exception as e:                                                   # noqa: BLE001
                 print("bench.py rank %d: weight broadcast failed (%s: %s); generating the weights locally" %
                       (rank, type(e).__name__, e), file=sys.stderr, flush=True)
@@ -361,12 +361,23 @@ def main():
     # one process per GPU: keep this rank's threads (2 pipeline threads + the rANS workers) on its share of the cores,
     # those of its GPU's NUMA node when sysfs tells - before anything touches the GPU
     cpus = dist_utils.pin_rank_threads(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else None
-    _lib.require_gpu()
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    n_dev = _lib.require_gpu()
+    # DCVC_BENCH_REHEARSE=1 (developer rehearsal of the N > 1 path on a ONE-GPU box, labelled on the line, never a
+    # measurement of configs[4]): the ranks share the GPUs there are (rank r on GPU r % count) and talk over gloo - RCCL
+    # refuses two ranks on one device.  Everything else is the real run: the real codecs, pinning, measure(), the line.
+    rehearse = world > 1 and os.environ.get("DCVC_BENCH_REHEARSE") == "1"
+    if world > 1 and local >= n_dev and not rehearse:
+        raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible): one rank per GPU" % (local, n_dev))
+    gpu = local % n_dev
+    torch.cuda.set_device(gpu)
+    device = torch.device("cuda", gpu)
+    coll_device = torch.device("cpu") if rehearse else device      # where the collectives' tensors live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     dtype = torch.float16
     torch.set_grad_enabled(False)
     # no intra-op thread pool (the reference harness does the same, src/utils/common.py:23): its idle workers compete with
@@ -374,7 +385,7 @@ def main():
     # 377 / 331 / 351 frames/s with the pool, 377 / 380 / 380 without (profiles/r04_host_threads_ab.txt)
     torch.set_num_threads(1)
 
-    (ie, pe), (idec, pdec) = load_models(dtype, device, world, rank)
+    (ie, pe), (idec, pdec) = load_models(dtype, device, world, rank, coll_device)
     two = use_two_entropy_coders(HEIGHT, WIDTH)
     for m in (ie, pe, idec, pdec):
         m.set_use_two_entropy_coders(two)
@@ -415,8 +426,8 @@ def main():
     # Placement of the timed window in the GOP (the encoder codes an I frame whenever its frame counter is a multiple
     # of 32): whole GOPs start on an I frame; a shorter window gets one I frame in its middle - never a P-only window.
     K = args.steps
-    elapsed, align, mine = measure(run_pipelined, K, args.warmup, world, device, torch.cuda.synchronize)
-    rank_fps = dist_utils.gather_over_ranks(K / mine, device, world)         # every rank's own frames/s (rank 0 reports)
+    elapsed, align, mine = measure(run_pipelined, K, args.warmup, world, coll_device, torch.cuda.synchronize)
+    rank_fps = dist_utils.gather_over_ranks(K / mine, coll_device, world)         # every rank's own frames/s (rank 0 reports)
     assert state["i"] % GOP == (window_start(K) + K) % GOP
     assert state["j"] == args.warmup + align + K
     assert state["n_i"] >= max(1, K // GOP), "the timed window must contain I frames at the GOP's rate"
@@ -480,8 +491,9 @@ def main():
         else:
             base = 1.0 / (1.0 / BASELINE_ENC_FPS + 1.0 / BASELINE_DEC_FPS)
         out = {
-            "metric": "%s YUV420 encode+decode FPS (frames/s through encode AND decode, whole job)"
-                      % ("1080p" if (WIDTH, HEIGHT) == (1920, 1080) else args.frame),
+            "metric": "%s%s YUV420 encode+decode FPS (frames/s through encode AND decode, whole job)"
+                      % ("REHEARSAL (%d ranks sharing %d GPU(s), gloo) - not a measurement of the multi-GPU configuration: "
+                         % (world, n_dev) if rehearse else "", "1080p" if (WIDTH, HEIGHT) == (1920, 1080) else args.frame),
             "value": round(value, 3), "unit": "frames/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": round(seq_value / base, 4), "dtype": "f16", "data": "synthetic",
