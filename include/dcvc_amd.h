@@ -144,6 +144,14 @@ int dcvc_yuv420_to_frame(int dtype, const uint8_t* y, const uint8_t* u, const ui
  * the reference's `.to(uint8)` unless round_uv. */
 int dcvc_frame_to_yuv420(int dtype, const void* x_nchw, int Hp, int Wp, int H, int W, int round_uv,
                          uint8_t* y, uint8_t* u, uint8_t* v, void* stream);
+/* PNG (RGB) sources of the reference harness: uint8 planar RGB [3][H][W] -> the padded YCbCr model input (/255, BT.709
+ * rgb2ycbcr in fp32 + clamp: src/utils/transforms.py:27-38, test_video.py:84-90, replicate pad :179) ... */
+int dcvc_rgb_to_frame(int dtype, const uint8_t* rgb, int H, int W, int pad_b, int pad_r, void* out_nchw,
+                      void* stream);
+/* ... and a reconstruction [3][Hp][Wp] -> clamp(ycbcr2rgb(x) * 255, 0, 255) of the HxW picture, [3][H][W] in the
+ * storage type (transforms.py:41-53, test_video.py:118-119; every operation rounded to the storage type like the
+ * reference's fp16 tensors): the values its RGB PSNR, MS-SSIM and PNG writer read. */
+int dcvc_frame_to_rgb(int dtype, const void* x_nchw, int Hp, int Wp, int H, int W, void* out_chw, void* stream);
 /* right/bottom edge replication on HWC: replicate_pad (cuda_inference.py:174-179), pad_for_y */
 int dcvc_replicate_pad_hwc(int dtype, const void* x, int64_t ldx, int H, int W, int C, int pad_b,
                            int pad_r, void* out, int64_t ldo, void* stream);

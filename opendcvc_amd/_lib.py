@@ -59,6 +59,8 @@ _SIGS = {
     "dcvc_shuffle8_clamp": (_I, [_I, _P, _L, _P, _I, _I, _I, _I, _P, _P]),
     "dcvc_yuv420_to_frame": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "dcvc_frame_to_yuv420": (_I, [_I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "dcvc_rgb_to_frame": (_I, [_I, _P, _I, _I, _I, _I, _P, _P]),
+    "dcvc_frame_to_rgb": (_I, [_I, _P, _I, _I, _I, _I, _P, _P]),
     "dcvc_replicate_pad_hwc": (_I, [_I, _P, _L, _I, _I, _I, _I, _I, _P, _L, _P]),
     "dcvc_scale_channels": (_I, [_I, _P, _L, _P, _L, _I, _P, _L, _P]),
     "dcvc_copy_channels": (_I, [_I, _P, _L, _L, _I, _P, _L, _P]),

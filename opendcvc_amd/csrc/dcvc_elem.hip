@@ -269,6 +269,63 @@ __global__ void frame_to_yuv420_kernel(const T* x, int HP, int WP, int H, int W,
     (c == 1 ? up : vp)[k] = (uint8_t)s;                                      // truncation like `.to(uint8)`
 }
 
+// ------------------------------------------------------------------ RGB (PNG sources) <-> model frame
+// ITU-R BT.709 weights as the reference's transforms.py:7-10 spells them; the scalars below are the fp32 values torch
+// uses when a Python float meets a float32 / float16 tensor.
+__device__ __forceinline__ void rgb_consts(float& kr, float& kg, float& kb)
+{
+    kr = 0.2126f;
+    kg = 0.7152f;
+    kb = 0.0722f;
+}
+
+// uint8 planar RGB [3][H][W] -> padded YCbCr model input: /255 (test_video.py:60-63), rgb2ycbcr in fp32 with the reference's
+// operation order and clamp (transforms.py:27-38), ONE rounding to the storage type (test_video.py:90), replicate pad (:179)
+template <typename T>
+__global__ void rgb_to_frame_kernel(const uint8_t* rgb, int H, int W, int HO, int WO, T* out)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= (int64_t)HO * WO) return;
+    const int xw = (int)(i % WO), y = (int)(i / WO);
+    const int sy = y < H ? y : H - 1, sx = xw < W ? xw : W - 1;
+    const int64_t sp = (int64_t)sy * W + sx, plane = (int64_t)H * W;
+    const float r = (float)rgb[sp] / 255.0f, g = (float)rgb[plane + sp] / 255.0f, b = (float)rgb[2 * plane + sp] / 255.0f;
+    float kr, kg, kb;
+    rgb_consts(kr, kg, kb);
+    const float yy = (kr * r + kg * g) + kb * b;
+    const float cb = (0.5f * (b - yy)) / (float)(1.0 - 0.0722) + 0.5f;
+    const float cr = (0.5f * (r - yy)) / (float)(1.0 - 0.2126) + 0.5f;
+    const int64_t op = (int64_t)HO * WO;
+    st(out, i, clampf(yy, 0.f, 1.f));
+    st(out, op + i, clampf(cb, 0.f, 1.f));
+    st(out, 2 * op + i, clampf(cr, 0.f, 1.f));
+}
+
+// reconstruction [3][HP][WP] (YCbCr) -> clamp(ycbcr2rgb(x) * 255, 0, 255) of the HxW picture as [3][H][W] in the storage type:
+// every operation of transforms.py:41-53 + test_video.py:118-119 rounded to the storage type like the reference's tensors
+// (fp16 reconstructions are converted in fp16 there); what the reference's RGB PSNR / MS-SSIM / PNG writer read
+template <typename T>
+__global__ void frame_to_rgb_kernel(const T* x, int HP, int WP, int H, int W, T* out)
+{
+    const int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x;
+    if (i >= (int64_t)H * W) return;
+    const int xw = (int)(i % W), y = (int)(i / W);
+    const int64_t sp = (int64_t)y * WP + xw, plane = (int64_t)HP * WP;
+    auto q = [](float v) { return (float)to_t<T>(v); };
+    const float yy = ld(x, sp), cb = ld(x, plane + sp), cr = ld(x, 2 * plane + sp);
+    float kr, kg, kb;
+    rgb_consts(kr, kg, kb);
+    // (a Python scalar next to a half tensor enters torch's kernels in fp32 - the op-math type - not rounded to fp16)
+    const float sr = (float)(2.0 - 2.0 * 0.2126), sb = (float)(2.0 - 2.0 * 0.0722);
+    const float r = q(yy + q(sr * q(cr - 0.5f)));
+    const float b = q(yy + q(sb * q(cb - 0.5f)));
+    const float g = q(q(q(yy - q(kr * r)) - q(kb * b)) / kg);
+    const int64_t op = (int64_t)H * W;
+    st(out, i, clampf(q(clampf(r, 0.f, 1.f) * 255.0f), 0.f, 255.f));
+    st(out, op + i, clampf(q(clampf(g, 0.f, 1.f) * 255.0f), 0.f, 255.f));
+    st(out, 2 * op + i, clampf(q(clampf(b, 0.f, 1.f) * 255.0f), 0.f, 255.f));
+}
+
 // ------------------------------------------------------------------ z quantiser
 template <typename T>
 __global__ void round_z_kernel(T* z, int64_t ldz, int64_t HW, int C, int8_t* z_chw)
@@ -897,6 +954,25 @@ int dcvc_frame_to_yuv420(int dtype, const void* x_nchw, int Hp, int Wp, int H, i
         using T = decltype(tag);
         frame_to_yuv420_kernel<T><<<nblocks((int64_t)H * W * 3 / 2), EB, 0, (hipStream_t)stream>>>(
             (const T*)x_nchw, Hp, Wp, H, W, round_uv, y, u, v);
+    });
+}
+
+int dcvc_rgb_to_frame(int dtype, const uint8_t* rgb, int H, int W, int pad_b, int pad_r, void* out_nchw, void* stream)
+{
+    DCVC_REQUIRE(rgb && out_nchw && H > 0 && W > 0 && pad_b >= 0 && pad_r >= 0, "dcvc_rgb_to_frame: bad arguments (%dx%d)", H, W);
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        rgb_to_frame_kernel<T><<<nblocks((int64_t)(H + pad_b) * (W + pad_r)), EB, 0, (hipStream_t)stream>>>(
+            rgb, H, W, H + pad_b, W + pad_r, (T*)out_nchw);
+    });
+}
+
+int dcvc_frame_to_rgb(int dtype, const void* x_nchw, int Hp, int Wp, int H, int W, void* out_chw, void* stream)
+{
+    DCVC_REQUIRE(x_nchw && out_chw && H > 0 && W > 0 && Hp >= H && Wp >= W, "dcvc_frame_to_rgb: bad arguments");
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        frame_to_rgb_kernel<T><<<nblocks((int64_t)H * W), EB, 0, (hipStream_t)stream>>>((const T*)x_nchw, Hp, Wp, H, W, (T*)out_chw);
     });
 }
 

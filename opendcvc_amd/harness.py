@@ -11,8 +11,9 @@ Restates (no code shared) the behaviour of the reference harness:
   test_video.py:381-442,472-532   the job fan-out: a JSON dataset manifest, one job per (sequence, rate point), a pool
                           of spawned worker processes (-w), worker n on GPU n % gpu_num, one merged JSON log
   src/utils/common.py:49-60      dump_json (floats with six digits)
-PNG sources and MS-SSIM are out of scope; the codec calls are the drop-in DMCI / DMC of
-opendcvc_amd.models.
+  test_video.py:66-127, src/utils/video_reader.py:10-47, transforms.py:27-53, metrics.py:9-79   PNG (RGB) sources: BT.709
+                          rgb <-> ycbcr around the codec, RGB PSNR; --calc_ssim: MS-SSIM per plane (YUV: (6 Y + U + V) / 8)
+The codec calls are the drop-in DMCI / DMC of opendcvc_amd.models.
 
     python -m opendcvc_amd.harness --test-config cfg.json -w 16 --gpus 8 --output-path out.json     # configs[4]
 """
@@ -58,6 +59,109 @@ def yuv420_distortion(x_hat, y, u, v):
     for rec, src in ((y_rec[0, 0], y), (uv_rec[0, 0], u), (uv_rec[0, 1], v)):
         out.append(psnr_from_mse(float(torch.mean(torch.square(rec.double() - src.double())))))
     return [(6 * out[0] + out[1] + out[2]) / 8] + out
+
+
+# MS-SSIM as the reference computes it for --calc_ssim (metrics.py:9-79: the multi-scale SSIM of Wang et al. with an 11x11 Gaussian
+# window, sigma 1.5, 'valid' windows, 2x2 box + decimation between the scales, four scales instead of five below 176 pixels -
+# "according to HM" - and none below 88).  Host numpy / scipy, like the reference's: a metric of the harness, not the hot path.
+_MSSSIM_WEIGHTS = {5: (0.0448, 0.2856, 0.3001, 0.2363, 0.1333), 4: (0.0517, 0.3295, 0.3462, 0.2726)}
+
+
+def _gauss_window(size=11, sigma=1.5):
+    ax = np.arange(size, dtype=np.float64) - size // 2
+    g = np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) / (2.0 * sigma * sigma))
+    return g / g.sum()
+
+
+def _ssim_and_cs(a, b, window, data_range):
+    from scipy import signal
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    local = lambda img: signal.fftconvolve(window, img, mode="valid")
+    mu_a, mu_b = local(a), local(b)
+    var_a, var_b, cov = local(a * a) - mu_a * mu_a, local(b * b) - mu_b * mu_b, local(a * b) - mu_a * mu_b
+    cs = (2.0 * cov + c2) / (var_a + var_b + c2)
+    return ((2 * mu_a * mu_b + c1) * (2 * cov + c2)) / ((mu_a * mu_a + mu_b * mu_b + c1) * (var_a + var_b + c2)), cs
+
+
+def calc_msssim(a, b, data_range=255):
+    """a, b: 2-D arrays (one plane each)"""
+    from scipy import ndimage
+    h, w = a.shape
+    if h < 88 or w < 88:
+        raise ValueError("MS-SSIM needs planes of at least 88 x 88 (the reference asserts)")
+    levels = 5 if (h >= 176 and w >= 176) else 4
+    weights = np.asarray(_MSSSIM_WEIGHTS[levels])
+    window, box = _gauss_window(), np.full((2, 2), 0.25)
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    ssim_mean, cs_mean = [], []
+    for _ in range(levels):
+        ssim_map, cs_map = _ssim_and_cs(a, b, window, data_range)
+        ssim_mean.append(ssim_map.mean())
+        cs_mean.append(cs_map.mean())
+        a = ndimage.convolve(a, box, mode="reflect")[::2, ::2]
+        b = ndimage.convolve(b, box, mode="reflect")[::2, ::2]
+    cs_mean, ssim_mean = np.asarray(cs_mean), np.asarray(ssim_mean)
+    with np.errstate(invalid="ignore"):       # (unrelated pictures: a negative contrast term to a fractional power is NaN, as in the reference)
+        return float(np.prod(cs_mean[:levels - 1] ** weights[:levels - 1]) * ssim_mean[levels - 1] ** weights[levels - 1])
+
+
+def calc_msssim_rgb(a, b, data_range=255):
+    """a, b: [3, H, W]; the mean over the three planes"""
+    return sum(calc_msssim(a[i], b[i], data_range) for i in range(3)) / 3
+
+
+def rgb_distortion(x_hat, rgb, calc_ssim=False):
+    """test_video.py:116-126 on the device: x_hat [1,3,H',W'] YCbCr (model dtype), rgb uint8 [3,H,W] (device) ->
+    ([psnr], [msssim]): clamp(ycbcr2rgb(x_hat) * 255, 0, 255) in the reconstruction's own dtype (one fused kernel), squared
+    errors in float64; MS-SSIM on the host."""
+    import torch
+    rec = reconstruct_rgb(x_hat, rgb.shape[1], rgb.shape[2])
+    psnr = psnr_from_mse(float(torch.mean(torch.square(rec.double() - rgb.double()))))
+    ms = calc_msssim_rgb(rgb.cpu().numpy(), rec.float().cpu().numpy().astype(np.float64)) if calc_ssim else 0.0
+    return [psnr], [ms]
+
+
+def reconstruct_rgb(x_hat, height, width):
+    """decoded [1,3,H',W'] YCbCr -> clamp(ycbcr2rgb * 255, 0, 255) of the height x width picture, [3,H,W] in x_hat's dtype
+    (transforms.py:41-53, test_video.py:118-119)"""
+    import ctypes
+    import torch
+    from . import _lib
+    from . import nn as L
+    x = x_hat.contiguous()
+    _, _, Hp, Wp = x.shape
+    out = torch.empty((3, height, width), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().dcvc_frame_to_rgb(L.dtype_code(x.dtype), L._p(x), Hp, Wp, height, width, L._p(out),
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "dcvc_frame_to_rgb")
+    return out
+
+
+def load_rgb_frame(rgb, dtype, pad_to=16):
+    """uint8 device tensor [3,H,W] (RGB) -> padded YCbCr model input [1,3,H',W'] (one fused kernel; reference:
+    np_image_to_tensor + rgb2ycbcr + the cast + replicate_pad, test_video.py:59-63,84-90,179)"""
+    import ctypes
+    import torch
+    from . import _lib
+    from . import nn as L
+    _, H, W = rgb.shape
+    pr, pb = (-W) % pad_to, (-H) % pad_to
+    out = torch.empty((1, 3, H + pb, W + pr), dtype=dtype, device=rgb.device)
+    _lib.check(_lib.lib().dcvc_rgb_to_frame(L.dtype_code(dtype), L._p(rgb.contiguous()), H, W, pb, pr, L._p(out),
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "dcvc_rgb_to_frame")
+    return out
+
+
+def yuv420_msssim(x_hat, y, u, v):
+    """--calc_ssim on a YUV 4:2:0 source (test_video.py:106-112): MS-SSIM of the planes yuv420_distortion compares, combined
+    (6 Y + U + V) / 8; host computation on the clamped, not rounded, planes"""
+    import torch
+    H, W = y.shape
+    x = x_hat[:, :, :H, :W]
+    y_rec = torch.clamp(x[:, :1] * 255, 0, 255)[0, 0]
+    uv_rec = torch.clamp(torch.nn.functional.avg_pool2d(x[:, 1:], 2) * 255, 0, 255)[0]
+    vals = [calc_msssim(src.cpu().numpy(), rec.float().cpu().numpy().astype(np.float64))
+            for rec, src in ((y_rec, y), (uv_rec[0], u), (uv_rec[1], v))]
+    return [(6 * vals[0] + vals[1] + vals[2]) / 8] + vals
 
 
 def summarize(frame_pixel_num, test_time, frame_types, bits, psnrs, ssims, verbose=False,
@@ -138,6 +242,34 @@ class YUV420FileReader:
         self.f.close()
 
 
+class PNGSequenceReader:
+    """a directory of im1.png, im2.png, ... or im00001.png, ... (video_reader.py:10-47): uint8 [3, H, W] RGB per frame"""
+
+    def __init__(self, path, width, height, start_num=1):
+        names = set(os.listdir(path))
+        if "im1.png" in names:
+            self.digits = 1
+        elif "im00001.png" in names:
+            self.digits = 5
+        else:
+            raise ValueError(f"{path}: unknown image naming convention (expected im1.png ... or im00001.png ...)")
+        self.path, self.w, self.h, self.index = path, width, height, start_num
+
+    def read(self):
+        from PIL import Image
+        name = os.path.join(self.path, "im%s.png" % str(self.index).zfill(self.digits))
+        if not os.path.exists(name):
+            raise EOFError("PNG sequence ended")
+        rgb = np.asarray(Image.open(name).convert("RGB"), np.uint8).transpose(2, 0, 1)
+        if rgb.shape != (3, self.h, self.w):
+            raise ValueError(f"{name}: {rgb.shape[2]}x{rgb.shape[1]}, expected {self.w}x{self.h}")
+        self.index += 1
+        return (rgb,)
+
+    def close(self):
+        pass
+
+
 def _to_device(planes, device):
     import torch
     return [torch.from_numpy(np.array(p, copy=True)).to(device) for p in planes]     # (the planes may be read-only views of the file buffer)
@@ -145,10 +277,18 @@ def _to_device(planes, device):
 
 # ---------------------------------------------------------------------------------- one rate point
 def run_one_point(i_net, p_net, src_path, width, height, frame_num, qp_i, qp_p=None, intra_period=-1,
-                  reset_interval=32, bin_path=None, rec_path=None, verbose=0, verbose_json=False, device="cuda:0"):
-    """Encodes `frame_num` frames of a YUV 4:2:0 file into the reference's container (optionally written to
-    bin_path), decodes the container again, and returns the reference-schema log.  i_net / p_net: DMCI / DMC
-    (weights loaded, .update() called, on `device`, optionally .half())."""
+                  reset_interval=32, bin_path=None, rec_path=None, verbose=0, verbose_json=False, device="cuda:0",
+                  src_type="yuv420", calc_ssim=False):
+    """Encodes `frame_num` frames of a YUV 4:2:0 file (src_type "yuv420") or of a directory of PNGs ("png": RGB, converted
+    to YCbCr around the codec) into the reference's container (optionally written to bin_path), decodes the container again,
+    and returns the reference-schema log.  i_net / p_net: DMCI / DMC (weights loaded, .update() called, on `device`,
+    optionally .half()).  calc_ssim: MS-SSIM per frame (host computation, slow) instead of zeros.  rec_path: the decoded
+    sequence as a planar YUV file / as PNGs in that directory."""
+    if src_type not in ("yuv420", "png"):
+        raise ValueError(f"src_type {src_type!r}: the reference harness reads 'yuv420' or 'png'")
+    png = src_type == "png"
+    make_reader = (lambda: PNGSequenceReader(src_path, width, height)) if png else (lambda: YUV420FileReader(src_path, width, height))
+    to_input = (lambda planes, dt: load_rgb_frame(planes[0], dt)) if png else (lambda planes, dt: load_yuv420_frame(*planes, dt))
     import torch
     dev = torch.device(device)
     dtype = next(p_net.parameters()).dtype
@@ -156,16 +296,16 @@ def run_one_point(i_net, p_net, src_path, width, height, frame_num, qp_i, qp_p=N
     for m in (i_net, p_net):
         m.set_use_two_entropy_coders(two)
     t_start = time.time()
-    reader = YUV420FileReader(src_path, width, height)
+    reader = make_reader()
     enc = SequenceEncoder(i_net, p_net, qp_i, qp_p, intra_period, reset_interval)
     out = io.BytesIO()
     writer = StreamWriter(out)
     frame_types, bits, enc_time, dec_time, psnrs, ssims = [], [], [], [], [], []
     for _ in range(frame_num):
-        y, u, v = _to_device(reader.read(), dev)
+        planes = _to_device(reader.read(), dev)
         torch.cuda.synchronize(dev)
         t0 = time.time()
-        pkt = enc.encode(load_yuv420_frame(y, u, v, dtype))
+        pkt = enc.encode(to_input(planes, dtype))
         bits.append(8 * writer.write_frame(height, width, two, pkt))
         torch.cuda.synchronize(dev)
         enc_time.append(time.time() - t0)
@@ -176,13 +316,17 @@ def run_one_point(i_net, p_net, src_path, width, height, frame_num, qp_i, qp_p=N
         with open(bin_path, "wb") as f:
             f.write(stream)
 
-    reader = YUV420FileReader(src_path, width, height)
+    reader = make_reader()
     stream_reader = StreamReader(io.BytesIO(stream))
-    rec = open(rec_path, "wb") if rec_path else None
+    rec = None
+    if rec_path and png:
+        os.makedirs(rec_path, exist_ok=True)
+    elif rec_path:
+        rec = open(rec_path, "wb")
     from .pipeline import FramePacket
     dec = SequenceDecoder(i_net, p_net, height, width, two)
-    for _ in range(frame_num):
-        y, u, v = _to_device(reader.read(), dev)
+    for fi in range(frame_num):
+        planes = _to_device(reader.read(), dev)
         torch.cuda.synchronize(dev)
         t0 = time.time()
         sps, is_i, qp, payload = stream_reader.read_frame()
@@ -190,8 +334,18 @@ def run_one_point(i_net, p_net, src_path, width, height, frame_num, qp_i, qp_p=N
         x_hat = dec.decode(FramePacket(is_i, qp, sps["use_ada_i"], payload))
         torch.cuda.synchronize(dev)
         dec_time.append(time.time() - t0)
+        if png:
+            p_, s_ = rgb_distortion(x_hat, planes[0], calc_ssim)
+            psnrs.append(p_)
+            ssims.append(s_)
+            if rec_path:        # clamp * 255 rounded to uint8 (test_video.py:314-318), names like the source's
+                from PIL import Image
+                rgb8 = reconstruct_rgb(x_hat, height, width).float().round().to(torch.uint8).cpu().numpy()
+                Image.fromarray(rgb8.transpose(1, 2, 0)).save(os.path.join(rec_path, "im%s.png" % str(fi + 1).zfill(reader.digits)))
+            continue
+        y, u, v = planes
         psnrs.append(yuv420_distortion(x_hat, y, u, v))
-        ssims.append([0.0, 0.0, 0.0, 0.0])
+        ssims.append(yuv420_msssim(x_hat, y, u, v) if calc_ssim else [0.0, 0.0, 0.0, 0.0])
         if rec is not None:     # clamp * 255, Y rounded, chroma truncated (test_video.py:307-311)
             for plane in store_yuv420_frame(x_hat, height, width):
                 rec.write(plane.cpu().numpy().tobytes())
@@ -244,8 +398,8 @@ def jobs_from_config(config, opts):
     for ds_name, ds in config["test_classes"].items():
         if ds["test"] == 0:
             continue
-        if ds["src_type"] != "yuv420":
-            raise ValueError(f"{ds_name}: only planar 8-bit YUV 4:2:0 sources are supported (src_type {ds['src_type']})")
+        if ds["src_type"] not in ("yuv420", "png"):
+            raise ValueError(f"{ds_name}: src_type {ds['src_type']!r} (the reference harness reads 'yuv420' or 'png')")
         for seq, info in ds["sequences"].items():
             for rate_idx, (q, qq) in enumerate(zip(qi, qp)):
                 ip = info["intra_period"]
@@ -255,7 +409,7 @@ def jobs_from_config(config, opts):
                 jobs.append(dict(ds_name=ds_name, seq=seq, rate_idx=rate_idx, qp_i=q, qp_p=qq,
                                  src_path=os.path.join(root, ds["base_path"], seq), src_width=info["width"],
                                  src_height=info["height"], frame_num=fn, intra_period=ip,
-                                 reset_interval=opts.get("reset_interval", 32)))
+                                 reset_interval=opts.get("reset_interval", 32), src_type=ds["src_type"]))
     return jobs
 
 
@@ -385,7 +539,7 @@ def run_job(nets, job, opts):
     return run_one_point(nets[0], nets[1], job["src_path"], job["src_width"], job["src_height"], job["frame_num"],
                          job["qp_i"], job["qp_p"], intra_period=job["intra_period"], reset_interval=job["reset_interval"],
                          bin_path=bin_path, verbose=opts.get("verbose", 0), verbose_json=opts.get("verbose_json", False),
-                         device="cuda:0")
+                         device="cuda:0", src_type=job.get("src_type", "yuv420"), calc_ssim=bool(opts.get("calc_ssim")))
 
 
 def _worker(job):
@@ -430,6 +584,9 @@ def main(argv=None):
     ap.add_argument("--force-intra-period", type=int, default=-1)
     ap.add_argument("--stream-path", help="write every point's container to <stream-path>/<dataset>/<sequence>_q<qp>.bin")
     ap.add_argument("--output-path", help="merged JSON log of the manifest run")
+    ap.add_argument("--calc-ssim", action="store_true", help="MS-SSIM per frame (reference --calc_ssim; host computation, slow)")
+    ap.add_argument("--src-type", choices=("yuv420", "png"), default="yuv420",
+                    help="--src is a planar 8-bit YUV 4:2:0 file, or a directory of im1.png ... / im00001.png ... (RGB)")
     ap.add_argument("--src")
     ap.add_argument("--width", type=int)
     ap.add_argument("--height", type=int)
@@ -459,7 +616,7 @@ def main(argv=None):
                     force_frame_num=args.force_frame_num, force_intra_period=args.force_intra_period,
                     reset_interval=args.reset_interval, model_i=args.model_i, model_p=args.model_p,
                     force_zero_thres=args.force_zero_thres, fp32=args.fp32, stream_path=args.stream_path,
-                    verbose=args.verbose, verbose_json=args.verbose_json)
+                    verbose=args.verbose, verbose_json=args.verbose_json, calc_ssim=args.calc_ssim)
         t0 = time.time()
         log = run_config(config, opts, workers=args.worker, gpus=gpus)
         out_path = args.output_path or args.out
@@ -498,7 +655,7 @@ def main(argv=None):
     res = run_sweep(make_nets, args.src, args.width, args.height, args.frames, args.rate_num,
                     args.qp_i or None, args.qp_p or None, bin_prefix=args.bin_prefix,
                     intra_period=args.intra_period, reset_interval=args.reset_interval, verbose=args.verbose,
-                    verbose_json=args.verbose_json)
+                    verbose_json=args.verbose_json, src_type=args.src_type, calc_ssim=args.calc_ssim)
     text = json.dumps({str(k): v for k, v in res.items()}, indent=2)
     if args.out:
         with open(args.out, "w") as f:
