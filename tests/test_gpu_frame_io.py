@@ -51,3 +51,40 @@ def test_full_size_round_trip_property(dtype):
     assert torch.equal(x[:, :, h:, :], x[:, :, h - 1:h, :].expand(-1, -1, 8, -1))
     y2, u2, v2 = store_yuv420_frame(x, h, w, round_uv=True)
     assert torch.equal(y2, y) and torch.equal(u2, u) and torch.equal(v2, v)
+
+
+# ------------------------------------------------------------------------------------------- RGB (PNG sources)
+@pytest.fixture(scope="module")
+def gold_rgb(golden_dir):
+    return np.load(os.path.join(golden_dir, "frame_io_rgb.npz"))
+
+
+@pytest.mark.parametrize("dtype,name", [(torch.float32, "f32"), (torch.float16, "f16")])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_rgb_to_padded_frame_matches_reference(gold_rgb, tag, dtype, name):
+    """uint8 RGB -> /255 -> rgb2ycbcr (BT.709, fp32, the reference's operation order) -> clamp -> cast -> replicate pad, bit for
+    bit what np_image_to_tensor + rgb2ycbcr + .to(float16) + replicate_pad give (tests/golden/make_golden_rgb.py)"""
+    from opendcvc_amd.harness import load_rgb_frame
+    got = load_rgb_frame(torch.from_numpy(gold_rgb[f"src_{tag}_rgb"]).cuda(), dtype)
+    want = gold_rgb[f"src_{tag}_{name}"]
+    assert got.dtype == dtype and tuple(got.shape) == want.shape
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("dtype,name", [(torch.float32, "f32"), (torch.float16, "f16")])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_frame_to_rgb_and_its_metrics_match_reference(gold_rgb, tag, dtype, name):
+    """clamp(ycbcr2rgb(x_hat) * 255, 0, 255) in the reconstruction's own dtype (fp16: every operation rounded like the reference's
+    half tensors), then the reference's RGB PSNR and MS-SSIM of it"""
+    from opendcvc_amd.harness import reconstruct_rgb, rgb_distortion
+    x = torch.from_numpy(gold_rgb[f"rec_{tag}_{name}_x"]).cuda()
+    rgb = torch.from_numpy(gold_rgb[f"src_{tag}_rgb"]).cuda()
+    _, h, w = rgb.shape
+    rec = reconstruct_rgb(x, h, w)
+    want = gold_rgb[f"rec_{tag}_{name}_rgb"]
+    assert rec.dtype == dtype and np.array_equal(rec.cpu().numpy(), want)
+    with_ssim = f"rec_{tag}_{name}_msssim" in gold_rgb.files
+    psnr, ms = rgb_distortion(x, rgb, calc_ssim=with_ssim)
+    assert psnr[0] == pytest.approx(float(gold_rgb[f"rec_{tag}_{name}_psnr"]), abs=1e-9)
+    if with_ssim:
+        assert ms[0] == pytest.approx(float(gold_rgb[f"rec_{tag}_{name}_msssim"]), abs=1e-12)

@@ -201,3 +201,67 @@ def test_manifest_run_two_workers_on_one_gpu_equals_one_worker(tmp_path, golden_
             for k in ("ave_all_frame_bpp", "ave_all_frame_psnr", "i_frame_num", "p_frame_num"):
                 assert a[k] == b[k], (seq, key, k)
     assert logs[1]["S"]["b_136x200.yuv"]["000"]["i_frame_num"] == 2
+
+
+def test_msssim_matches_reference_values(golden_dir):
+    """harness.calc_msssim / calc_msssim_rgb (own restatement of metrics.py:9-79) against values the reference's functions
+    produced (tests/golden/make_golden_rgb.py): five scales, four scales (< 176 pixels), the 176 boundary, the RGB mean"""
+    g = np.load(os.path.join(golden_dir, "frame_io_rgb.npz"))
+    for tag in ("l5", "l4", "edge"):
+        assert harness.calc_msssim(g[f"ms_{tag}_a"], g[f"ms_{tag}_b"]) == pytest.approx(float(g[f"ms_{tag}_val"]), abs=1e-12)
+    assert harness.calc_msssim_rgb(g["src_c_rgb"], g["rec_c_f32_rgb"]) == pytest.approx(float(g["rec_c_f32_msssim"]), abs=1e-12)
+    with pytest.raises(ValueError):
+        harness.calc_msssim(np.zeros((64, 200)), np.zeros((64, 200)))        # the reference asserts below 88 pixels
+
+
+def test_png_sequence_reader(tmp_path, golden_dir):
+    import sys
+    sys.path.insert(0, golden_dir)
+    from make_golden_png import synthetic_rgb, write_png_sequence
+    for digits in (1, 5):
+        folder = str(tmp_path / f"seq{digits}")
+        write_png_sequence(folder, 48, 32, 3, 7, digits=digits)
+        r = harness.PNGSequenceReader(folder, 48, 32)
+        for fi in range(3):
+            (rgb,) = r.read()
+            assert rgb.dtype == np.uint8 and rgb.shape == (3, 32, 48) and np.array_equal(rgb, synthetic_rgb(32, 48, fi, 7))
+        with pytest.raises(EOFError):
+            r.read()
+    with pytest.raises(ValueError):
+        harness.PNGSequenceReader(str(tmp_path), 48, 32)                      # no im1.png / im00001.png here
+    with pytest.raises(ValueError):
+        harness.PNGSequenceReader(str(tmp_path / "seq1"), 64, 32).read()      # size mismatch
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fp32", "fp16"])
+def test_png_rate_point_with_msssim_matches_reference(tmp_path, golden_dir, mode):
+    """The reference harness's PNG branch (RGB source -> YCbCr around the codec, RGB PSNR, --calc_ssim MS-SSIM): one rate point of
+    a 4-frame 96 x 128 sequence against the log the REFERENCE's run_one_point_with_stream wrote for it
+    (tests/golden/make_golden_png.py -> png_point.json).  Same keys in the same order; fp32: frames within one byte, PSNR
+    within 1e-4 dB, MS-SSIM within 1e-4; fp16: the usual 4 % / 0.05 dB / 5e-3."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    from make_golden_png import write_png_sequence
+    gold = json.load(open(os.path.join(golden_dir, "png_point.json")))
+    cfg = gold["config"]
+    W, H, N = cfg["width"], cfg["height"], cfg["frames"]
+    src = str(tmp_path / "seq")
+    write_png_sequence(src, W, H, N, cfg["src_seed"])
+    i_net, p_net = _nets(mode)
+    got = harness.run_one_point(i_net, p_net, src, W, H, N, cfg["qp"], intra_period=cfg["intra_period"],
+                                reset_interval=cfg["reset_interval"], bin_path=str(tmp_path / "o.bin"), verbose_json=True,
+                                src_type="png", calc_ssim=True, rec_path=str(tmp_path / "rec"))
+    refs = [gold["fp32"]] + ([gold["fp16"]] if mode == "fp16" else [])
+    assert list(got.keys()) == refs[0]["keys"], "log schema differs from the reference's"
+    assert sorted(os.listdir(tmp_path / "rec")) == [f"im{k:05d}.png" for k in range(1, N + 1)]
+    for ref in refs:
+        want = ref["log"]
+        assert got["frame_type"] == want["frame_type"]
+        for fi in range(N):
+            gb, wb = got["frame_bpp"][fi] * H * W, want["frame_bpp"][fi] * H * W
+            assert abs(gb - wb) <= (8 if mode == "fp32" else 0.04 * wb + 8), (fi, gb, wb)
+            assert abs(got["frame_psnr"][fi] - want["frame_psnr"][fi]) < (1e-4 if mode == "fp32" else 0.05)
+            assert abs(got["frame_msssim"][fi] - want["frame_msssim"][fi]) < (1e-4 if mode == "fp32" else 5e-3)
+        for k in ("ave_all_frame_bpp", "ave_all_frame_psnr", "ave_all_frame_msssim"):
+            assert got[k] == pytest.approx(want[k], rel=1e-3 if mode == "fp32" else 0.02), k
