@@ -85,7 +85,7 @@ struct Wcfg {
     static constexpr int STREAM = FRAGS + PADF;       // + dummies: the ring refill never needs a clamp
 };
 
-template <int C, class G = G128>
+template <int C, class G = G128, bool HEADIN = false>
 struct Cfg : Wcfg<C> {
     using GE = Geo<G>;
     using WC = Wcfg<C>;
@@ -101,7 +101,12 @@ struct Cfg : Wcfg<C> {
     // is 90 KB of requests per slab for the depthwise taps alone): depthwise taps [9][C] halfs, depthwise bias [C] floats,
     // FFN bias [4 C] floats
     static constexpr size_t TAB_BYTES = (size_t)9 * C * 2 + (size_t)C * 4 + (size_t)4 * C * 4;
-    static constexpr size_t LDS = ((size_t)GE::M * LDX + v_elems) * sizeof(half_t) + TAB_BYTES;
+    // HEADIN (the block's own first conv computed here on the tile + halo): the input rows of the halo pixels, padded to whole
+    // 32-pixel MFMA column blocks, behind the tables
+    static constexpr int HROWS = (GE::HALO + 31) / 32 * 32;
+    static constexpr size_t HEAD_BYTES = HEADIN ? (size_t)HROWS * LDX * sizeof(half_t) : 0;
+    static_assert(!HEADIN || C == G::DW_SLAB, "HEADIN: the activation a of the whole halo tile must be one depthwise slab");
+    static constexpr size_t LDS = ((size_t)GE::M * LDX + v_elems) * sizeof(half_t) + TAB_BYTES + HEAD_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(NCH % 2 == 0 && NCH >= 4, "the chunk loop is unrolled by two");
     static_assert((2 * C) % VC == 0, "whole FFN chunks");
@@ -124,11 +129,15 @@ __device__ __forceinline__ floatx16 mfma32(const half8& a, const half8& b, const
 // C/D layout of the 32x32 tile: lane (pl = lane & 31 -> pixel, hh = lane >> 5), register reg -> row (channel)
 // (reg & 3) + 8 (reg >> 2) + 4 hh: four quads of 4 consecutive channels at 8 g + 4 hh, g = 0..3.
 
-template <int C, class G = G128>
+// HEADIN (32-pixel tiles, width 128, block without adaptor and not fed by a fused head): a = gate(W1 x + b1) is computed here
+// on the tile and its 1-pixel halo - 60 of 64 GEMM columns - from the block's input x (p.hx) and the W1 fragment stream the
+// fused-head tails use (p.hwt), instead of by a head launch; pixels outside the picture get a = 0 (the depthwise conv's zero
+// padding).  Same k order, bias, gate and fp16 rounding as the head kernels: the same `a`.
+template <int C, class G = G128, bool HEADIN = false>
 __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailParams p)
 {
     using TR = Traits<half_t>;
-    using CF = Cfg<C, G>;
+    using CF = Cfg<C, G, HEADIN>;
     using GE = Geo<G>;
     // (the geometry's values under the names the code below was written with: they shadow the namespace-level G128 constants)
     constexpr int TW = GE::TW, TH = GE::TH, M = GE::M, NTHR = GE::NTHR, PTW = GE::PTW, HALO = GE::HALO, DW_SLAB = GE::DW_SLAB,
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
         bd0 = *reinterpret_cast<const floatx4*>(tabBd + c);
         bd1 = *reinterpret_cast<const floatx4*>(tabBd + c + 4);
     };
-    fetch(0);
+    if constexpr (!HEADIN) fetch(0);
     // the small tables -> LDS (visible after the first barrier of the depthwise stage); requested behind slab 0, in
     // front of the other slabs: their LDS stores wait for nothing else
     {
@@ -215,8 +224,82 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
             reinterpret_cast<Vec16*>(tabW)[i] = *src;      // (the three tables are contiguous in LDS)
         }
     }
+    if constexpr (!HEADIN) {
 #pragma unroll
-    for (int sl = 1; sl < nslab; ++sl) fetch(sl);
+        for (int sl = 1; sl < nslab; ++sl) fetch(sl);
+    }
+    if constexpr (HEADIN) {
+        // x on the tile + halo -> LDS rows (halo pixel order, zero beyond the picture / the halo), then W1 x on the matrix pipe:
+        // this wave's channel tiles x the HROWS / 32 pixel blocks, + b1, gate, fp16 -> the (single) depthwise slab buffer
+        constexpr int HROWS = CF::HROWS, HT = HROWS / 32, NLX = (HROWS * GC + NTHR - 1) / NTHR;
+        half_t* xs = reinterpret_cast<half_t*>(reinterpret_cast<char*>(tabW) + CF::TAB_BYTES);
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(p.hx), 0, (int)((long)p.H * p.W * p.ldhx * 2), 0x00020000);
+        Vec16 xv[NLX];
+#pragma unroll
+        for (int k = 0; k < NLX; ++k) {
+            const int it = tid + k * NTHR, hp = it / GC, c = (it % GC) * V;
+            const int y = ty0 - 1 + hp / HW_, x = tx0 - 1 + hp % HW_;
+            const int off = (hp < HALO && y >= 0 && y < p.H && x >= 0 && x < p.W) ? ((y * p.W + x) * (int)p.ldhx + c) * 2 : OOB;
+            xv[k] = __builtin_bit_cast(Vec16, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0));
+        }
+        const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.hwt)) + (size_t)cqw * (KS * NTW + PADF) * 1024, 0,
+            (KS * NTW + PADF) * 1024, 0x00020000);
+        half8 hfrag[KS * NTW];
+        static_assert(KS * NTW <= 16, "HEADIN keeps W1's fragments of the wave in registers");
+#pragma unroll
+        for (int k = 0; k < KS * NTW; ++k) {
+            typedef unsigned u32x4h __attribute__((ext_vector_type(4)));
+            hfrag[k] = __builtin_bit_cast(half8, (u32x4h)__builtin_amdgcn_raw_buffer_load_b128(hrsrc, wlane, k * 1024, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < NLX; ++k) {
+            const int it = tid + k * NTHR, hp = it / GC, c = (it % GC) * V;
+            if (hp < HROWS) *reinterpret_cast<Vec16*>(xs + hp * LDX + c) = xv[k];
+        }
+        __syncthreads();
+        floatx16 hacc[NTW][HT];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            half8 hb_[HT];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) hb_[t] = *reinterpret_cast<const half8*>(xs + (32 * t + pl) * LDX + 8 * hh + 16 * s);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    if (s == 0) {
+                        floatx16 zero;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                        hacc[i][t] = mfma32(hfrag[s * NTW + i], hb_[t], zero);
+                    } else {
+                        hacc[i][t] = mfma32(hfrag[s * NTW + i], hb_[t], hacc[i][t]);
+                    }
+                }
+        }
+        half_t* hb0 = bufV;          // slab 0's halo buffer: [HALO][LDS_S], one slab = every channel
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const int chb = 32 * (cqw + 4 * i) + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const floatx4 bias = load_f4(p.hb1 + chb + 8 * g);
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    const int hp = 32 * t + pl;
+                    const int y = ty0 - 1 + hp / HW_, x = tx0 - 1 + hp % HW_;
+                    const bool inside = hp < HALO && y >= 0 && y < p.H && x >= 0 && x < p.W;
+                    floatx4 v = {hacc[i][t][4 * g], hacc[i][t][4 * g + 1], hacc[i][t][4 * g + 2], hacc[i][t][4 * g + 3]};
+                    v = v + bias;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = inside ? TR::gate(v[r]) : 0.f;
+                    if (hp < HALO) lds_store_quad<half_t>(hb0, LDS_S, hp, chb + 8 * g, v);
+                }
+            }
+        }
+    }
     constexpr int NID = M * GC / NTHR;
     // identity / output pass: item k of this thread -> pixel m = tid / 8 + (NTHR / 8) (k / G8), channel group tid % 8 + 8 (k % G8)
     // (eight threads cover 128 contiguous bytes of a pixel; no division per item, nothing to keep in registers)
@@ -281,12 +364,14 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
 #pragma unroll
         for (int slab = 0; slab < nslab; ++slab) {
             half_t* hb = bufV + (slab & 1) * (HALO * LDS_S);
+            if constexpr (!HEADIN) {
 #pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int hp = tid / GS + k * (NTHR / GS);
-                if (hp < HALO) *reinterpret_cast<Vec16*>(hb + hp * LDS_S + dcs) = pre[slab][k];
+                for (int k = 0; k < NLD; ++k) {
+                    const int hp = tid / GS + k * (NTHR / GS);
+                    if (hp < HALO) *reinterpret_cast<Vec16*>(hb + hp * LDS_S + dcs) = pre[slab][k];
+                }
             }
-            if (slab == nslab - 2) ident_fetch();   // (registers of the first slabs are free again; two slabs of time to arrive)
+            if (slab == (nslab >= 2 ? nslab - 2 : 0)) ident_fetch();   // (registers of the first slabs are free again; two slabs of time to arrive - one at a single-slab width)
             if (slab == nslab - 1) {                // first turn of the weight ring: lands underneath this slab
 #pragma unroll
                 for (int k = 0; k < D; ++k) ring[k] = wload();

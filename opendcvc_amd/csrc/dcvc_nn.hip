@@ -229,6 +229,7 @@ struct TailParams {
     long ldhx;
     const void* hw1;
     const float* hb1;
+    const void* hwt;     // dcb_tail128_kernel<..., HEADIN>: W1 as the per-quarter fragment stream (the one a fused-head tail reads)
     const void* wt;      // dcb_tail128_kernel: the tail's weights as per-quarter fragment streams (dcb_t128.hpp)
     const void* nwt;     // ... and the fused next-block head's / 1x1 conv's (the same matrix as nw1, 32x32x16 fragments)
     int ablate;          // debug: bit0 skip dw, bit1 skip GEMM2, bit2 skip FFN GEMM3, bit3 skip FFN GEMM4
@@ -1041,7 +1042,7 @@ int pack_t128(DevBuf& dst, const std::function<float(int, int)>& W2, const std::
     return dst.upload(buf.data(), buf.size() * sizeof(half_t));
 }
 
-inline bool t128_width_ok(int c_p) { return c_p == 256 || c_p == 320 || c_p == 384 || c_p == 512; }   // (512: 32-pixel tiles only)
+inline bool t128_width_ok(int c_p) { return c_p == 128 || c_p == 256 || c_p == 320 || c_p == 384 || c_p == 512; }   // (128, 512: 32-pixel tiles only)
 
 // a C x C matrix (next block's first conv, a fused 1x1 conv) as the per-quarter fragment stream gemm_c reads
 template <int C>
@@ -1105,7 +1106,7 @@ inline int pack_t128_conv(DevBuf& dst, int ntw, int taps, int padf, int Np, int 
 
 inline int pack_t128_square_any(int c_p, DevBuf& dst, const std::function<float(int, int)>& W)
 {
-    return c_p == 256 ? pack_t128_square<256>(dst, W) : c_p == 320 ? pack_t128_square<320>(dst, W)
+    return c_p == 128 ? pack_t128_square<128>(dst, W) : c_p == 256 ? pack_t128_square<256>(dst, W) : c_p == 320 ? pack_t128_square<320>(dst, W)
                       : c_p == 384 ? pack_t128_square<384>(dst, W) : pack_t128_square<512>(dst, W);
 }
 
@@ -1122,18 +1123,24 @@ static bool t32_enabled()    // DCVC_T32=0: small-map tails (widths 256 / 384) b
     return on;
 }
 
+static bool t32_128_enabled()    // DCVC_T32_128=0: width-128 blocks by dcb_tail_kernel<..., HEADIN> (A/B measurements, bit-identity checks)
+{
+    static const bool on = !(getenv("DCVC_T32_128") && atoi(getenv("DCVC_T32_128")) == 0);
+    return on;
+}
+
 static bool h128_enabled()   // DCVC_H128=0: large-map heads by dcb_head_kernel (A/B measurements, bit-identity checks)
 {
     static const bool on = !(getenv("DCVC_H128") && atoi(getenv("DCVC_H128")) == 0);
     return on;
 }
 
-template <int C, class G = t128::G128>
+template <int C, class G = t128::G128, bool HEADIN = false>
 int launch_tail128(const TailParams& tp, int H, int W, hipStream_t st)
 {
     const int grid = ((H + G::TH - 1) / G::TH) * ((W + G::TW - 1) / G::TW);
-    const size_t lds = t128::Cfg<C, G>::LDS;
-    int rc = set_lds(t128::dcb_tail128_kernel<C, G>, lds);
+    const size_t lds = t128::Cfg<C, G, HEADIN>::LDS;
+    int rc = set_lds(t128::dcb_tail128_kernel<C, G, HEADIN>, lds);
     if (rc) return rc;
 #ifdef DCVC_DIAG      // developer build only (make diag): in-kernel phase stamps, median over the workgroups
     static const bool want_stamps = getenv("DCVC_STAMPS") != nullptr;
@@ -1141,7 +1148,7 @@ int launch_tail128(const TailParams& tp, int H, int W, hipStream_t st)
         TailParams q = tp;
         q.ablate = getenv("DCVC_ABLATE") ? atoi(getenv("DCVC_ABLATE")) : 0;     // timing experiments (wrong results)
         DCVC_HIP(hipMalloc(&q.stamps, (size_t)grid * 16 * sizeof(unsigned long long)));
-        hipLaunchKernelGGL((t128::dcb_tail128_kernel<C, G>), dim3(grid), dim3(t128::Geo<G>::NTHR), lds, st, q);
+        hipLaunchKernelGGL((t128::dcb_tail128_kernel<C, G, HEADIN>), dim3(grid), dim3(t128::Geo<G>::NTHR), lds, st, q);
         DCVC_HIP(hipStreamSynchronize(st));
         std::vector<unsigned long long> hs((size_t)grid * 16);
         DCVC_HIP(hipMemcpy(hs.data(), q.stamps, hs.size() * 8, hipMemcpyDeviceToHost));
@@ -1166,7 +1173,7 @@ int launch_tail128(const TailParams& tp, int H, int W, hipStream_t st)
         return 0;
     }
 #endif
-    hipLaunchKernelGGL((t128::dcb_tail128_kernel<C, G>), dim3(grid), dim3(t128::Geo<G>::NTHR), lds, st, tp);
+    hipLaunchKernelGGL((t128::dcb_tail128_kernel<C, G, HEADIN>), dim3(grid), dim3(t128::Geo<G>::NTHR), lds, st, tp);
     return 0;
 }
 
@@ -1218,7 +1225,15 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         const bool fuse_ok = ch.next ? ch.next->w1_t128.p != nullptr : ch.conv ? ch.conv->w_t128.p != nullptr : true;
         t32 = h->wt128.p != nullptr && t128_enabled() && t32_enabled() && fuse_ok;
     }
-    const bool head_in = kHeadInKernel && !ch.head_done && !ch.separate_head && !h->adapt && src.c1 == 0 && !t32;
+    // ... and width 128 (the hyper path's blocks: 17x30 ... 68x120 maps): the same tail with the block's first conv computed
+    // inside on the tile + halo (dcb_tail128_kernel<128, G32, HEADIN>) where today's dcb_tail_kernel<..., HEADIN> runs
+    bool t32h = false;
+    if constexpr (sizeof(T) == 2 && MT == 2 && NTW == 2) {
+        const bool fuse_ok = ch.next ? ch.next->w1_t128.p != nullptr : ch.conv ? ch.conv->w_t128.p != nullptr : true;
+        t32h = h->wt128.p != nullptr && h->w1_t128.p != nullptr && t128_enabled() && t32_enabled() && t32_128_enabled() && fuse_ok &&
+               !ch.head_done && !ch.separate_head && !h->adapt && src.c1 == 0;
+    }
+    const bool head_in = kHeadInKernel && !ch.head_done && !ch.separate_head && !h->adapt && src.c1 == 0 && !t32 && !t32h;
     if (ev) DCVC_HIP(hipEventRecord(ev[0], st));
     // widths 256 / 320 / 384 on large maps, 256 / 384 / 512 in front of the 32-pixel tails: the head in the form of dcb_t128.hpp
     // (sources of 64-channel multiples)
@@ -1250,7 +1265,7 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
             }
         }
     }
-    if (ch.head_done || head_in || head128) {
+    if (ch.head_done || head_in || head128 || t32h) {
         // `a` was written by the previous block's tail / is computed by this block's tail / by the 128-pixel head
     } else if (h->adapt) {
         // two sources: one at a time through LDS (half the staging buffer: a 64-pixel tile of 256 + 256 channels then
@@ -1301,11 +1316,12 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
     tp.q = quant;
     tp.out = out;
     tp.ldo = ldo;
-    if (head_in) {
+    if (head_in || t32h) {
         tp.hx = src.x0;
         tp.ldhx = src.ld0;
         tp.hw1 = h->w1.p;
         tp.hb1 = (const float*)h->b1.p;
+        tp.hwt = h->w1_t128.p;
     }
     if (ch.next) {
         tp.nw1 = ch.next->w1.p;
@@ -1333,6 +1349,17 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         tp.stamps = d_stamps;
     }
 #endif
+    if constexpr (sizeof(T) == 2 && MT == 2 && NTW == 2) {
+        if (t32h) {
+            tp.wt = h->wt128.p;
+            tp.nwt = ch.next ? ch.next->w1_t128.p : ch.conv ? ch.conv->w_t128.p : nullptr;
+            int rc = launch_tail128<128, t128::G32, true>(tp, H, W, st);
+            if (rc) return rc;
+            DCVC_LAUNCH_CHECK();
+            if (ev) DCVC_HIP(hipEventRecord(ev[2], st));
+            return 0;
+        }
+    }
     if constexpr (sizeof(T) == 2 && MT == 2 && (NTW == 4 || NTW == 6 || NTW == 8)) {
         if (t32) {
             tp.wt = h->wt128.p;
@@ -1636,11 +1663,11 @@ int dcvc_dcb_create(int dtype, int cin, int c, int shortcut, const float* adapto
         auto W4 = [&](int n, int k) { return (n < C && k < 2 * C) ? w4[(size_t)n * 2 * C + k] / ka : 0.f; };
         if (h->adapt && Kp % 64 == 0) {
             auto WA = [&](int n, int k) { return (n < C && k < cin) ? adaptor_w[(size_t)n * cin + k] : 0.f; };
-            rc |= Cp == 256 ? pack_t128_rect<256>(h->wa_t128, Kp, WA) : Cp == 320 ? pack_t128_rect<320>(h->wa_t128, Kp, WA)
+            rc |= Cp == 128 ? pack_t128_rect<128>(h->wa_t128, Kp, WA) : Cp == 256 ? pack_t128_rect<256>(h->wa_t128, Kp, WA) : Cp == 320 ? pack_t128_rect<320>(h->wa_t128, Kp, WA)
                             : Cp == 384 ? pack_t128_rect<384>(h->wa_t128, Kp, WA) : pack_t128_rect<512>(h->wa_t128, Kp, WA);
         }
         rc |= pack_t128_square_any(Cp, h->w1_t128, [&](int n, int k) { return (n < C && k < C) ? ka * w1[(size_t)n * C + k] : 0.f; });
-        rc |= Cp == 256 ? pack_t128<256>(h->wt128, W2, W3, W4) : Cp == 320 ? pack_t128<320>(h->wt128, W2, W3, W4)
+        rc |= Cp == 128 ? pack_t128<128>(h->wt128, W2, W3, W4) : Cp == 256 ? pack_t128<256>(h->wt128, W2, W3, W4) : Cp == 320 ? pack_t128<320>(h->wt128, W2, W3, W4)
                         : Cp == 384 ? pack_t128<384>(h->wt128, W2, W3, W4) : pack_t128<512>(h->wt128, W2, W3, W4);
     }
     if (rc) return rc < 0 ? rc : dcvc::E_MEM;

@@ -204,11 +204,13 @@ def test_chained_blocks_equal_separate_calls(c, hw, dtype):
 
 
 def _small_map_outputs():
-    """fp16 blocks on maps below 12 000 pixels, widths 256 / 368 (-> 384): a 4-block chain behind an adaptor block (fused
-    heads, quant at the end), a shortcut + quant block, a 2-block chain ending in a fused 1x1 conv with quant"""
+    """fp16 blocks on maps below 12 000 pixels, widths 256 / 368 (-> 384) / 512 / 128: a 4-block chain behind an adaptor block
+    (fused heads, quant at the end), a shortcut + quant block, a 2-block chain ending in a fused 1x1 conv with quant.  (Width 128:
+    the blocks without adaptor and without a head computed by their predecessor take dcb_tail128_kernel<128, G32, HEADIN> - the
+    head inside - unless DCVC_T32=0 / DCVC_T32_128=0.)"""
     from opendcvc_amd import _lib, nn
     outs = []
-    for c, (H, W) in ((256, (21, 19)), (368, (12, 27)), (512, (14, 20)), (256, (68, 120))):
+    for c, (H, W) in ((256, (21, 19)), (368, (12, 27)), (512, (14, 20)), (256, (68, 120)), (128, (17, 30)), (128, (35, 61))):
         rng = _rng(4000 + c + H)
         blocks = [nn.DepthConvBlock(make_dcb_weights(rng, "m", 2 * c if i == 0 else c, c, i == 0), "m", torch.float16) for i in range(4)]
         x0 = to_dev(rng.standard_normal((H, W, 2 * c)).astype(np.float32), blocks[0].cin_p, torch.float16)
@@ -226,8 +228,9 @@ def _small_map_outputs():
 
 
 def test_tail32_equals_tail_kernel_bitwise(tmp_path):
-    """The 32-pixel form of dcb_tail128_kernel (small maps, widths 256 / 384) stores and rounds where dcb_tail_kernel does and
-    accumulates in the same k order: identical outputs with DCVC_T32=0 (a separate process: the switch is read once)."""
+    """The 32-pixel form of dcb_tail128_kernel (small maps, widths 256 / 384 / 512, and 128 with its head computed inside) stores
+    and rounds where dcb_tail_kernel does and accumulates in the same k order: identical outputs with DCVC_T32=0 (a separate
+    process: the switch is read once)."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     outs = {}

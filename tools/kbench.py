@@ -110,7 +110,9 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "mix":
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "chain":
-    if len(sys.argv) > 3:
+    if len(sys.argv) > 5:          # chain C n H W
+        run_chain(int(sys.argv[2]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[3]))
+    elif len(sys.argv) > 3:
         run_chain(int(sys.argv[2]), 68, 120, int(sys.argv[3]))
     else:
         for C in (256, 384):
