@@ -265,3 +265,25 @@ def test_png_rate_point_with_msssim_matches_reference(tmp_path, golden_dir, mode
             assert abs(got["frame_msssim"][fi] - want["frame_msssim"][fi]) < (1e-4 if mode == "fp32" else 5e-3)
         for k in ("ave_all_frame_bpp", "ave_all_frame_psnr", "ave_all_frame_msssim"):
             assert got[k] == pytest.approx(want[k], rel=1e-3 if mode == "fp32" else 0.02), k
+
+
+@pytest.mark.gpu
+def test_yuv420_msssim_matches_reference(tmp_path, golden_dir):
+    """--calc_ssim on a YUV 4:2:0 source (test_video.py:106-112: MS-SSIM per plane on the clamped reconstruction planes, combined
+    (6 Y + U + V) / 8) against the REFERENCE's log of a 176 x 192 sequence (png_point.json, key yuv420_msssim), fp32"""
+    import sys
+    sys.path.insert(0, golden_dir)
+    from make_golden_sweep import write_yuv420
+    gold = json.load(open(os.path.join(golden_dir, "png_point.json")))["yuv420_msssim"]
+    cfg, want = gold["config"], gold["log"]
+    W, H, N = cfg["width"], cfg["height"], cfg["frames"]
+    src = str(tmp_path / "seq.yuv")
+    write_yuv420(src, W, H, N, cfg["src_seed"])
+    i_net, p_net = _nets("fp32")
+    got = harness.run_one_point(i_net, p_net, src, W, H, N, cfg["qp"], intra_period=cfg["intra_period"],
+                                reset_interval=cfg["reset_interval"], verbose_json=True, calc_ssim=True)
+    assert list(got.keys()) == gold["keys"]
+    for k in ("frame_msssim", "frame_msssim_y", "frame_msssim_u", "frame_msssim_v", "frame_psnr"):
+        for fi in range(N):
+            assert abs(got[k][fi] - want[k][fi]) < 1e-4, (k, fi, got[k][fi], want[k][fi])
+    assert got["ave_all_frame_msssim"] == pytest.approx(want["ave_all_frame_msssim"], abs=1e-4)
