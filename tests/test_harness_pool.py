@@ -34,8 +34,12 @@ def test_jobs_follow_the_manifest_and_the_overrides():
     assert [j["qp_i"] for j in jobs[:4]] == [0, 21, 42, 63] and [j["qp_p"] for j in jobs[:4]] == [1, 2, 3, 4]
     assert all(j["frame_num"] == 2 and j["intra_period"] == 8 for j in jobs)
     assert jobs[0]["src_path"] == "/data/a/one_64x64.yuv"
+    assert all(j["src_type"] == "yuv420" for j in jobs)
+    png = json.loads(json.dumps(GOLD["config"]))
+    png["test_classes"]["SetA"]["src_type"] = "png"          # the reference's other source type: a directory of PNGs per sequence
+    assert [j["src_type"] for j in harness.jobs_from_config(png, {})][:4] == ["png"] * 4
     bad = json.loads(json.dumps(GOLD["config"]))
-    bad["test_classes"]["SetA"]["src_type"] = "png"
+    bad["test_classes"]["SetA"]["src_type"] = "rgb24"
     with pytest.raises(ValueError):
         harness.jobs_from_config(bad, {})
 
