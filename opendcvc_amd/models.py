@@ -824,6 +824,10 @@ class DMC(CompressionModel):
         """video_model.py:343-376.  Five captured runs, separated by the three host decoding steps
         (z, first and second checkerboard half).
 
+        A damaged payload raises DcvcError after the frame's last symbol (entropy coder end-state check); the frame is then
+        not added to the DPB (a pending deferred picture of the PREVIOUS frame stays retrievable through finish_output()):
+        resume at the next I frame (clear_dpb()).
+
         defer_output=True (not in the reference API): the reconstruction network of THIS frame is not run now
         but in the two host-decoding gaps of the next call (nothing else can use the GPU there: the next
         frame's symbols are not known yet) - the returned dict then carries the PREVIOUS frame under
