@@ -95,8 +95,10 @@ struct Cfg : Wcfg<C> {
     // compile-time offset into the ring
     static constexpr int D = G::D;
     static_assert(D <= PADF, "stream padding");
-    static constexpr size_t v_elems = (size_t)2 * GE::M * LDV > (size_t)2 * GE::HALO * GE::LDS_S ? (size_t)2 * GE::M * LDV
-                                                                                                  : (size_t)2 * GE::HALO * GE::LDS_S;
+    // bufV: the two v chunk buffers of the FFN, earlier the halo slabs of the depthwise stage - two alternating ones, or (HEADIN)
+    // every slab of the activation a computed in the kernel
+    static constexpr size_t slab_elems = (size_t)(HEADIN && C / G::DW_SLAB > 2 ? C / G::DW_SLAB : 2) * GE::HALO * GE::LDS_S;
+    static constexpr size_t v_elems = (size_t)2 * GE::M * LDV > slab_elems ? (size_t)2 * GE::M * LDV : slab_elems;
     // small tables staged in LDS once (every thread needs them, 8 - 64 threads each the same 16 bytes: through the L1 that
     // is 90 KB of requests per slab for the depthwise taps alone): depthwise taps [9][C] halfs, depthwise bias [C] floats,
     // FFN bias [4 C] floats
@@ -105,7 +107,6 @@ struct Cfg : Wcfg<C> {
     // 32-pixel MFMA column blocks, behind the tables
     static constexpr int HROWS = (GE::HALO + 31) / 32 * 32;
     static constexpr size_t HEAD_BYTES = HEADIN ? (size_t)HROWS * LDX * sizeof(half_t) : 0;
-    static_assert(!HEADIN || C == G::DW_SLAB, "HEADIN: the activation a of the whole halo tile must be one depthwise slab");
     static constexpr size_t LDS = ((size_t)GE::M * LDX + v_elems) * sizeof(half_t) + TAB_BYTES + HEAD_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(NCH % 2 == 0 && NCH >= 4, "the chunk loop is unrolled by two");
@@ -129,7 +130,7 @@ __device__ __forceinline__ floatx16 mfma32(const half8& a, const half8& b, const
 // C/D layout of the 32x32 tile: lane (pl = lane & 31 -> pixel, hh = lane >> 5), register reg -> row (channel)
 // (reg & 3) + 8 (reg >> 2) + 4 hh: four quads of 4 consecutive channels at 8 g + 4 hh, g = 0..3.
 
-// HEADIN (32-pixel tiles, width 128, block without adaptor and not fed by a fused head): a = gate(W1 x + b1) is computed here
+// HEADIN (32-pixel tiles, block without adaptor and not fed by a fused head): a = gate(W1 x + b1) is computed here
 // on the tile and its 1-pixel halo - 60 of 64 GEMM columns - from the block's input x (p.hx) and the W1 fragment stream the
 // fused-head tails use (p.hwt), instead of by a head launch; pixels outside the picture get a = 0 (the depthwise conv's zero
 // padding).  Same k order, bias, gate and fp16 rounding as the head kernels: the same `a`.
@@ -246,13 +247,17 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
         const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char*>(reinterpret_cast<const char*>(p.hwt)) + (size_t)cqw * (KS * NTW + PADF) * 1024, 0,
             (KS * NTW + PADF) * 1024, 0x00020000);
-        half8 hfrag[KS * NTW];
-        static_assert(KS * NTW <= 16, "HEADIN keeps W1's fragments of the wave in registers");
-#pragma unroll
-        for (int k = 0; k < KS * NTW; ++k) {
+        // W1's fragments of this wave (KS x NTW, k-step major) through the ring registers the tail's streams use later
+        constexpr int NF = KS * NTW, HD = NF < D ? NF : D;
+        int hoff = 0;
+        auto hload = [&]() __attribute__((always_inline)) {
             typedef unsigned u32x4h __attribute__((ext_vector_type(4)));
-            hfrag[k] = __builtin_bit_cast(half8, (u32x4h)__builtin_amdgcn_raw_buffer_load_b128(hrsrc, wlane, k * 1024, 0));
-        }
+            const u32x4h v = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, wlane, hoff, 0);
+            hoff += 1024;
+            return __builtin_bit_cast(half8, v);
+        };
+#pragma unroll
+        for (int k = 0; k < HD; ++k) ring[k] = hload();
 #pragma unroll
         for (int k = 0; k < NLX; ++k) {
             const int it = tid + k * NTHR, hp = it / GC, c = (it % GC) * V;
@@ -266,20 +271,23 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
 #pragma unroll
             for (int t = 0; t < HT; ++t) hb_[t] = *reinterpret_cast<const half8*>(xs + (32 * t + pl) * LDX + 8 * hh + 16 * s);
 #pragma unroll
-            for (int i = 0; i < NTW; ++i)
+            for (int i = 0; i < NTW; ++i) {
+                const int f = s * NTW + i, k = f % HD;
 #pragma unroll
                 for (int t = 0; t < HT; ++t) {
                     if (s == 0) {
                         floatx16 zero;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-                        hacc[i][t] = mfma32(hfrag[s * NTW + i], hb_[t], zero);
+                        hacc[i][t] = mfma32(ring[k], hb_[t], zero);
                     } else {
-                        hacc[i][t] = mfma32(hfrag[s * NTW + i], hb_[t], hacc[i][t]);
+                        hacc[i][t] = mfma32(ring[k], hb_[t], hacc[i][t]);
                     }
                 }
+                if (f + HD < NF) ring[k] = hload();
+            }
         }
-        half_t* hb0 = bufV;          // slab 0's halo buffer: [HALO][LDS_S], one slab = every channel
+        // a -> the slab buffers [slab][HALO][LDS_S] the depthwise stage reads (HEADIN keeps every slab, nothing is staged later)
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             const int chb = 32 * (cqw + 4 * i) + 4 * hh;
@@ -295,7 +303,8 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
                     v = v + bias;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = inside ? TR::gate(v[r]) : 0.f;
-                    if (hp < HALO) lds_store_quad<half_t>(hb0, LDS_S, hp, chb + 8 * g, v);
+                    const int ch = chb + 8 * g;
+                    if (hp < HALO) lds_store_quad<half_t>(bufV + (ch / DW_SLAB) * (HALO * LDS_S), LDS_S, hp, ch % DW_SLAB, v);
                 }
             }
         }
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(Geo<G>::NTHR, G::WPS) void dcb_tail128_kernel(TailP
         const int pp = tid / GS, py = 2 * (pp / TW), px = pp % TW;      // pixel pair -> rows py, py + 1, column px of the tile
 #pragma unroll
         for (int slab = 0; slab < nslab; ++slab) {
-            half_t* hb = bufV + (slab & 1) * (HALO * LDS_S);
+            half_t* hb = bufV + (HEADIN ? slab : (slab & 1)) * (HALO * LDS_S);
             if constexpr (!HEADIN) {
 #pragma unroll
                 for (int k = 0; k < NLD; ++k) {

@@ -1129,6 +1129,12 @@ static bool t32_128_enabled()    // DCVC_T32_128=0: width-128 blocks by dcb_tail
     return on;
 }
 
+static bool t32h_enabled()      // DCVC_T32H=0: width 256 keeps its separate head launch in front of the 32-pixel tail (A/B)
+{
+    static const bool on = !(getenv("DCVC_T32H") && atoi(getenv("DCVC_T32H")) == 0);
+    return on;
+}
+
 static bool h128_enabled()   // DCVC_H128=0: large-map heads by dcb_head_kernel (A/B measurements, bit-identity checks)
 {
     static const bool on = !(getenv("DCVC_H128") && atoi(getenv("DCVC_H128")) == 0);
@@ -1225,13 +1231,16 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         const bool fuse_ok = ch.next ? ch.next->w1_t128.p != nullptr : ch.conv ? ch.conv->w_t128.p != nullptr : true;
         t32 = h->wt128.p != nullptr && t128_enabled() && t32_enabled() && fuse_ok;
     }
-    // ... and width 128 (the hyper path's blocks: 17x30 ... 68x120 maps): the same tail with the block's first conv computed
-    // inside on the tile + halo (dcb_tail128_kernel<128, G32, HEADIN>) where today's dcb_tail_kernel<..., HEADIN> runs
+    // ... with the block's first conv computed inside on the tile + halo (dcb_tail128_kernel<C, G32, HEADIN>) where the block has no
+    // adaptor and its head was not computed by its predecessor: width 128 (the hyper path's blocks on 17x30 ... 68x120 maps, where
+    // dcb_tail_kernel<..., HEADIN> ran before) and width 256 (one launch of 21.5 us instead of 6.1 + 17.5 us at 68x120; at width
+    // 384 the head on the 60-pixel halo tile costs more than the head launch it saves: 41.9 against 8.0 + 32.1 us - not used)
     bool t32h = false;
-    if constexpr (sizeof(T) == 2 && MT == 2 && NTW == 2) {
+    if constexpr (sizeof(T) == 2 && MT == 2 && (NTW == 2 || NTW == 4)) {
         const bool fuse_ok = ch.next ? ch.next->w1_t128.p != nullptr : ch.conv ? ch.conv->w_t128.p != nullptr : true;
-        t32h = h->wt128.p != nullptr && h->w1_t128.p != nullptr && t128_enabled() && t32_enabled() && t32_128_enabled() && fuse_ok &&
-               !ch.head_done && !ch.separate_head && !h->adapt && src.c1 == 0;
+        t32h = h->wt128.p != nullptr && h->w1_t128.p != nullptr && t128_enabled() && t32_enabled() && fuse_ok &&
+               (NTW == 2 ? t32_128_enabled() : t32h_enabled()) && !ch.head_done && !ch.separate_head && !h->adapt && src.c1 == 0;
+        if (t32h) t32 = false;
     }
     const bool head_in = kHeadInKernel && !ch.head_done && !ch.separate_head && !h->adapt && src.c1 == 0 && !t32 && !t32h;
     if (ev) DCVC_HIP(hipEventRecord(ev[0], st));
@@ -1243,7 +1252,7 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         constexpr bool kSmall = sizeof(T) == 2 && MT == 2 && (NTW == 4 || NTW == 6 || NTW == 8);
         if constexpr (kLarge || kSmall) {
             using G = typename std::conditional<kLarge, t128::G128, t128::G32>::type;
-            head128 = t128_enabled() && h128_enabled() && (kLarge || t32) && !ch.head_done && !head_in && h->w1_t128.p != nullptr &&
+            head128 = t128_enabled() && h128_enabled() && (kLarge || t32) && !t32h && !ch.head_done && !head_in && h->w1_t128.p != nullptr &&
                       (h->adapt ? (h->wa_t128.p != nullptr && src.c0 % 64 == 0 && src.c1 % 64 == 0 && kin == h->cin_p)
                                 : (src.c1 == 0 && src.c0 == NTW * 64));
             if (head128) {
@@ -1349,11 +1358,11 @@ int launch_dcb(const dcvc_dcb* h, const SrcPair& src, int H, int W, const float*
         tp.stamps = d_stamps;
     }
 #endif
-    if constexpr (sizeof(T) == 2 && MT == 2 && NTW == 2) {
+    if constexpr (sizeof(T) == 2 && MT == 2 && (NTW == 2 || NTW == 4)) {
         if (t32h) {
             tp.wt = h->wt128.p;
             tp.nwt = ch.next ? ch.next->w1_t128.p : ch.conv ? ch.conv->w_t128.p : nullptr;
-            int rc = launch_tail128<128, t128::G32, true>(tp, H, W, st);
+            int rc = launch_tail128<NTW * 64, t128::G32, true>(tp, H, W, st);
             if (rc) return rc;
             DCVC_LAUNCH_CHECK();
             if (ev) DCVC_HIP(hipEventRecord(ev[2], st));
