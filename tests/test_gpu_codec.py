@@ -110,16 +110,17 @@ def test_fp32_1080p_matches_reference_record(seqs):
 
 
 def test_fp16_1080p_close_to_reference_record(seqs):
-    """the benchmarked mode at the benchmarked size: rate within 2 %, PSNR within 0.05 dB of the reference's
-    fp32 record, decoder features bit-identical to the encoder's"""
+    """the benchmarked mode at the benchmarked size: rate within 0.5 %, PSNR within 0.005 dB of the reference's
+    fp32 record (measured: +0.06 % / +0.18 % / -0.16 %, 3e-4 dB; round 3 accepted 2 % / 0.05 dB), decoder features
+    bit-identical to the encoder's"""
     rec = seqs["seq_1088x1920"]
     got = run_hip(rec, torch.float16)
     for fi, g in enumerate(got):
         f = rec["frames"][fi]
         if fi > 0:
             assert np.array_equal(g["dec_feature"], g["feature"]), f"frame {fi}: fp16 enc/dec desync"
-        assert abs(len(g["bits"]) - f["bytes"]) <= 0.02 * f["bytes"], (fi, len(g["bits"]), f["bytes"])
-        assert abs(psnr_of(rec, fi, g["x_hat"]) - f["psnr"]) < 0.05, (fi, psnr_of(rec, fi, g["x_hat"]), f["psnr"])
+        assert abs(len(g["bits"]) - f["bytes"]) <= 0.005 * f["bytes"], (fi, len(g["bits"]), f["bytes"])
+        assert abs(psnr_of(rec, fi, g["x_hat"]) - f["psnr"]) < 0.005, (fi, psnr_of(rec, fi, g["x_hat"]), f["psnr"])
 
 
 def test_fp16_1080p_against_the_references_own_fp16_run(golden_dir):
