@@ -481,3 +481,31 @@ def test_damaged_payload_raises_instead_of_decoding_garbage():
     pdc.add_ref_frame(None, di["x_hat"])
     dp = pdc.decompress(ep["bit_stream"], sps, 30)
     assert torch.equal(pdc.dpb[0].feature, pe.dpb[0].feature) and dp["x_hat"] is not None
+
+
+@pytest.mark.parametrize("mode,dtype", [("fp32", torch.float32), ("fp16", torch.float16)])
+def test_1080p_nine_frames_stay_on_the_reference_record(golden_dir, mode, dtype):
+    """Parity along the temporal chain at the benchmarked size: I + 8 P frames at 1088 x 1920 with a feature refresh every 4
+    frames, against the REFERENCE's records of the same sequence in the same arithmetic (its fp32 run / its .half() run on the
+    CPU, tests/golden/make_golden_1080p_long.py -> seq_1080p_long.json).  Bounds per frame - fp32: bytes within 0.1 %, PSNR within
+    1e-3 dB; fp16: bytes within 0.5 %, PSNR within 0.005 dB; the encoder's and the decoder's features stay bit-identical.  The
+    measured deviations go to gpurun_out/seq_1080p_long_<mode>.json (profiles/r04_seq_1080p_long_<mode>.json)."""
+    gold = json.load(open(os.path.join(golden_dir, "seq_1080p_long.json")))
+    rec = dict(h=gold["h"], w=gold["w"], qp=gold["qp"], two=gold["two"], reset_interval=gold["reset_interval"], seed=gold["seed"],
+               thres=gold["thres"], frames=gold[mode])
+    got = run_hip(rec, dtype)
+    devs = []
+    for fi, g in enumerate(got):
+        f = rec["frames"][fi]
+        if fi > 0:
+            assert np.array_equal(g["dec_feature"], g["feature"]), f"frame {fi}: enc/dec feature desync"
+        devs.append(dict(frame=fi, type=f["type"], use_ada_i=f["use_ada_i"], bytes_ref=f["bytes"], bytes=len(g["bits"]),
+                         rel=round((len(g["bits"]) - f["bytes"]) / f["bytes"], 6), psnr_ref=f["psnr"],
+                         psnr=psnr_of(rec, fi, g["x_hat"]), identical=hashlib.sha256(g["bits"]).hexdigest() == f["sha256"]))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(dict(frames=devs), open(os.path.join(out, f"seq_1080p_long_{mode}.json"), "w"), indent=1)
+    tol_b, tol_p = (1e-3, 1e-3) if mode == "fp32" else (5e-3, 5e-3)
+    for d in devs:
+        assert abs(d["rel"]) <= tol_b, d
+        assert abs(d["psnr"] - d["psnr_ref"]) < tol_p, d
