@@ -509,3 +509,30 @@ def test_1080p_nine_frames_stay_on_the_reference_record(golden_dir, mode, dtype)
     for d in devs:
         assert abs(d["rel"]) <= tol_b, d
         assert abs(d["psnr"] - d["psnr_ref"]) < tol_p, d
+
+
+@pytest.mark.parametrize("mode,dtype", [("fp32", torch.float32), ("fp16", torch.float16)])
+def test_4k_matches_the_reference_record(golden_dir, mode, dtype):
+    """BASELINE.json configs[3]'s size: an I and a P frame at 3840 x 2160 (no padding: 2160 = 16 x 135; y 135 x 240 is padded to
+    136 x 240 for the hyper path) against the REFERENCE's records in the same arithmetic (tests/golden/seq_2160p.json, its fp32
+    run and its .half() run).  fp32: bytes within 0.1 %, PSNR within 1e-3 dB; fp16: 0.5 % / 0.005 dB; deviations in
+    gpurun_out/seq_2160p_<mode>.json (profiles/r04_seq_2160p_<mode>.json)."""
+    gold = json.load(open(os.path.join(golden_dir, "seq_2160p.json")))
+    rec = dict(h=gold["h"], w=gold["w"], qp=gold["qp"], two=gold["two"], reset_interval=gold["reset_interval"], seed=gold["seed"],
+               thres=gold["thres"], frames=gold[mode])
+    got = run_hip(rec, dtype)
+    devs = []
+    for fi, g in enumerate(got):
+        f = rec["frames"][fi]
+        if fi > 0:
+            assert np.array_equal(g["dec_feature"], g["feature"]), f"frame {fi}: enc/dec feature desync"
+        devs.append(dict(frame=fi, type=f["type"], bytes_ref=f["bytes"], bytes=len(g["bits"]),
+                         rel=round((len(g["bits"]) - f["bytes"]) / f["bytes"], 6), psnr_ref=f["psnr"],
+                         psnr=psnr_of(rec, fi, g["x_hat"]), identical=hashlib.sha256(g["bits"]).hexdigest() == f["sha256"]))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(dict(frames=devs), open(os.path.join(out, f"seq_2160p_{mode}.json"), "w"), indent=1)
+    tol_b, tol_p = (1e-3, 1e-3) if mode == "fp32" else (5e-3, 5e-3)
+    for d in devs:
+        assert abs(d["rel"]) <= tol_b, d
+        assert abs(d["psnr"] - d["psnr_ref"]) < tol_p, d
