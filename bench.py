@@ -28,6 +28,8 @@ Extra objects on the line:
   exact_mode   the fp32 mode that is bit-exact with the CPU oracle: P-frame encode / decode fps and the fraction of the
                157.3 TFLOP/s fp32 MFMA peak.
   gop_weighted_value   32 / (t_I + 31 t_P) from the timed window: does not depend on --steps.
+  reference_gop        bpp / PSNR of the same GOP coded by the reference in .half() on a CPU (fixture tests/golden/bench_gop_f16.json)
+               and this line's deviation from it.
 """
 import argparse
 import ctypes
@@ -533,6 +535,20 @@ def main():
                              "test_video.py:94-111); synthetic untrained weights: single-digit dB by construction - the "
                              "number pins parity with the reference (tests/golden), not picture quality"},
         }
+        # the same GOP coded by the REFERENCE in its fp16 arithmetic on a CPU (tests/golden/make_golden_bench_gop.py): how far the
+        # line's bpp / PSNR are from it (data file only; nothing of the reference runs here)
+        ref_path = os.path.join(REPO, "tests", "golden", "bench_gop_f16.json")
+        if (WIDTH, HEIGHT) == (1920, 1080) and os.path.exists(ref_path):
+            try:
+                ref = json.load(open(ref_path))
+                out["reference_gop"] = {
+                    "bpp": round(ref["gop_bpp"], 5), "psnr_weighted_6y_u_v": round(ref["psnr_mean"][0], 4),
+                    "bpp_rel_dev": round(out["gop_bpp"] / ref["gop_bpp"] - 1.0, 5),
+                    "psnr_dev_db": round(out["psnr"]["weighted_6y_u_v"] - ref["psnr_mean"][0], 5),
+                    "note": "the reference's DMCI / DMC in .half() on a CPU on the same 32 frames, qp and weights "
+                            "(tests/golden/bench_gop_f16.json): gop_bpp and psnr of this line against it"}
+            except Exception:      # noqa: BLE001  (a missing / unreadable fixture must not cost the measurement)
+                pass
         # whole-frame fractions (conv-hook GFLOP and fused-unit algorithmic bytes of a steady P frame at
         # 1088x1920, scaled by the padded pixel count) from the per-direction times of the sequential pass
         scale = ((WIDTH + (-WIDTH) % 16) * (HEIGHT + (-HEIGHT) % 16)) / (1920.0 * 1088.0)
