@@ -287,3 +287,42 @@ def test_yuv420_msssim_matches_reference(tmp_path, golden_dir):
         for fi in range(N):
             assert abs(got[k][fi] - want[k][fi]) < 1e-4, (k, fi, got[k][fi], want[k][fi])
     assert got["ave_all_frame_msssim"] == pytest.approx(want["ave_all_frame_msssim"], abs=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fp32", "fp16"])
+def test_qp_sweep_at_1080p_matches_reference_rd_points(tmp_path, golden_dir, mode):
+    """BASELINE.json configs[2] at its real size: the qp sweep {0, 21, 42, 63} of a 1920 x 1080 YUV 4:2:0 file (4 frames, qp tables
+    that span a 16:1 range) through harness.run_sweep against the log the REFERENCE's run_one_point_with_stream wrote for it
+    (tests/golden/make_golden_sweep.py --1080p -> sweep_1080p.json; "fp32": its fp32 run, "fp16": its .half() run on the CPU).
+    Same log keys; per frame bytes within 0.1 % (fp32) / 0.5 % (fp16) and PSNR (all, y, u, v) within 1e-3 / 0.005 dB; per point
+    bpp within 0.05 % / 0.3 %.  The points go to gpurun_out/sweep_1080p_<mode>.json."""
+    import hashlib
+    import sys
+    sys.path.insert(0, golden_dir)
+    from make_golden_sweep import write_yuv420
+    gold = json.load(open(os.path.join(golden_dir, "sweep_1080p.json")))
+    cfg = gold["config"]
+    W, H, N = cfg["width"], cfg["height"], cfg["frames"]
+    src = str(tmp_path / "seq.yuv")
+    write_yuv420(src, W, H, N, cfg["src_seed"])
+    assert hashlib.sha256(open(src, "rb").read()).hexdigest() == gold["src_sha256"]
+    logs = harness.run_sweep(lambda: _nets(mode, True), src, W, H, N, qp_i=cfg["qps"], intra_period=cfg["intra_period"],
+                             reset_interval=cfg["reset_interval"], verbose_json=True)
+    tol_b, tol_p, tol_pt = (1e-3, 1e-3, 5e-4) if mode == "fp32" else (5e-3, 5e-3, 3e-3)
+    summary = {}
+    for qp in cfg["qps"]:
+        got, ref = logs[qp], gold[mode][str(qp)]
+        want = ref["log"]
+        assert [k for k in got.keys() if k not in ("qp_i", "qp_p")] == ref["keys"], "log schema differs from the reference's"
+        assert got["frame_type"] == want["frame_type"]
+        for fi in range(N):
+            assert abs(got["frame_bpp"][fi] / want["frame_bpp"][fi] - 1) <= tol_b, (qp, fi, got["frame_bpp"][fi], want["frame_bpp"][fi])
+            for k in ("frame_psnr", "frame_psnr_y", "frame_psnr_u", "frame_psnr_v"):
+                assert abs(got[k][fi] - want[k][fi]) < tol_p, (qp, fi, k, got[k][fi], want[k][fi])
+        assert abs(got["ave_all_frame_bpp"] / want["ave_all_frame_bpp"] - 1) <= tol_pt, (qp, got["ave_all_frame_bpp"], want["ave_all_frame_bpp"])
+        summary[str(qp)] = dict(bpp=got["ave_all_frame_bpp"], bpp_ref=want["ave_all_frame_bpp"], psnr=got["ave_all_frame_psnr"],
+                                psnr_ref=want["ave_all_frame_psnr"])
+    out = os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(summary, open(os.path.join(out, f"sweep_1080p_{mode}.json"), "w"), indent=1)
