@@ -524,7 +524,18 @@ class DMC(CompressionModel):
         n["fusion"] = [D(sd, f"y_prior_fusion.conv.{i}", dt) for i in range(3)]
         n["fusion_out"] = C2(sd, "y_prior_fusion.conv.3", dt)
         n["spatial"] = [D(sd, "y_spatial_prior.conv.0", dt), D(sd, "y_spatial_prior.conv.1", dt)]
-        n["spatial_out"] = C2(sd, "y_spatial_prior.conv.2", dt)
+        # y_spatial_prior's last conv is 384 -> 256: as a SQUARE 384 -> 384 conv (128 all-zero output rows, never read) it qualifies
+        # for the fused launch inside the preceding block's tail (Conv2d.fusable_after) - the same dot products for the real
+        # channels, one 12 - 14 us launch less per coded frame on the decoder's critical path (DCVC_SQUARE_SPATIAL_OUT=0: as is)
+        w, b = sd["y_spatial_prior.conv.2.weight"], sd["y_spatial_prior.conv.2.bias"]
+        if os.environ.get("DCVC_SQUARE_SPATIAL_OUT") != "0" and w.shape[0] < w.shape[1] and w.shape[2:] == (1, 1):
+            wp = torch.zeros((w.shape[1], w.shape[1], 1, 1), dtype=w.dtype)
+            wp[:w.shape[0]] = w
+            bp = torch.zeros(w.shape[1], dtype=b.dtype)
+            bp[:b.shape[0]] = b
+            n["spatial_out"] = C2({"c.weight": wp, "c.bias": bp}, "c", dt)
+        else:
+            n["spatial_out"] = C2(sd, "y_spatial_prior.conv.2", dt)
         n["dec_up"] = L.SubpelConv2x(sd, "decoder.up", dt, 1)
         n["dec_conv1"] = [D(sd, f"decoder.conv1.{i}", dt) for i in range(3)]
         n["dec_conv2"] = C2(sd, "decoder.conv2", dt, epilogue=_lib.EPI_BIAS_QUANT)
