@@ -403,6 +403,8 @@ def jobs_from_config(config, opts):
         for seq, info in ds["sequences"].items():
             for rate_idx, (q, qq) in enumerate(zip(qi, qp)):
                 ip = info["intra_period"]
+                if opts.get("force_intra"):                      # every frame an I frame (test_video.py:490-491)
+                    ip = 1
                 if opts.get("force_intra_period", 0) > 0:
                     ip = opts["force_intra_period"]
                 fn = opts["force_frame_num"] if opts.get("force_frame_num", 0) > 0 else info["frames"]
@@ -530,16 +532,34 @@ def default_nets(opts):
 
 
 def run_job(nets, job, opts):
-    """one (sequence, rate point) on this worker's GPU -> the reference-schema log of the point"""
-    bin_path = None
+    """one (sequence, rate point) on this worker's GPU -> the reference-schema log of the point (test_video.py:354-379 worker +
+    :130-137, 251-255, 345-346): with a stream folder the point's container <stream_path>/<dataset>/<sequence>_q<qp>.bin and its log
+    <...>.json are written; check_existing returns the stored log of a point whose container and log exist with the right
+    frame count instead of coding it again; save_decoded_frame writes the reconstruction beside them (<...>.yuv, or PNGs in
+    the dataset's stream folder for PNG sources)."""
+    bin_path = json_path = rec_path = None
     if opts.get("stream_path"):
         folder = os.path.join(opts["stream_path"], job["ds_name"])
         os.makedirs(folder, exist_ok=True)
         bin_path = os.path.join(folder, f"{job['seq']}_q{job['qp_i']}.bin")         # test_video.py:364-367
-    return run_one_point(nets[0], nets[1], job["src_path"], job["src_width"], job["src_height"], job["frame_num"],
-                         job["qp_i"], job["qp_p"], intra_period=job["intra_period"], reset_interval=job["reset_interval"],
-                         bin_path=bin_path, verbose=opts.get("verbose", 0), verbose_json=opts.get("verbose_json", False),
-                         device="cuda:0", src_type=job.get("src_type", "yuv420"), calc_ssim=bool(opts.get("calc_ssim")))
+        json_path = bin_path[:-4] + ".json"
+        if opts.get("save_decoded_frame"):
+            rec_path = folder if job.get("src_type") == "png" else bin_path[:-4] + ".yuv"
+        if opts.get("check_existing") and os.path.exists(json_path) and os.path.exists(bin_path):
+            with open(json_path) as f:
+                log = json.load(f)
+            if log.get("i_frame_num", 0) + log.get("p_frame_num", 0) == job["frame_num"]:
+                return log
+            print(f"incorrect log for {json_path}, try to rerun.")
+    log = run_one_point(nets[0], nets[1], job["src_path"], job["src_width"], job["src_height"], job["frame_num"],
+                        job["qp_i"], job["qp_p"], intra_period=job["intra_period"], reset_interval=job["reset_interval"],
+                        bin_path=bin_path, rec_path=rec_path, verbose=opts.get("verbose", 0),
+                        verbose_json=opts.get("verbose_json", False), device="cuda:0", src_type=job.get("src_type", "yuv420"),
+                        calc_ssim=bool(opts.get("calc_ssim")))
+    if json_path:
+        with open(json_path, "w") as f:
+            json.dump(log, f, indent=2)
+    return log
 
 
 def _worker(job):
@@ -585,6 +605,11 @@ def main(argv=None):
     ap.add_argument("--stream-path", help="write every point's container to <stream-path>/<dataset>/<sequence>_q<qp>.bin")
     ap.add_argument("--output-path", help="merged JSON log of the manifest run")
     ap.add_argument("--calc-ssim", action="store_true", help="MS-SSIM per frame (reference --calc_ssim; host computation, slow)")
+    ap.add_argument("--force-intra", action="store_true", help="every frame an I frame (reference --force_intra)")
+    ap.add_argument("--check-existing", action="store_true",
+                    help="with --stream-path: do not code a point again whose .bin and .json exist (reference --check_existing)")
+    ap.add_argument("--save-decoded-frame", action="store_true",
+                    help="with --stream-path: write the reconstruction beside the .bin (reference --save_decoded_frame)")
     ap.add_argument("--src-type", choices=("yuv420", "png"), default="yuv420",
                     help="--src is a planar 8-bit YUV 4:2:0 file, or a directory of im1.png ... / im00001.png ... (RGB)")
     ap.add_argument("--src")
@@ -616,7 +641,8 @@ def main(argv=None):
                     force_frame_num=args.force_frame_num, force_intra_period=args.force_intra_period,
                     reset_interval=args.reset_interval, model_i=args.model_i, model_p=args.model_p,
                     force_zero_thres=args.force_zero_thres, fp32=args.fp32, stream_path=args.stream_path,
-                    verbose=args.verbose, verbose_json=args.verbose_json, calc_ssim=args.calc_ssim)
+                    verbose=args.verbose, verbose_json=args.verbose_json, calc_ssim=args.calc_ssim,
+                    force_intra=args.force_intra, check_existing=args.check_existing, save_decoded_frame=args.save_decoded_frame)
         t0 = time.time()
         log = run_config(config, opts, workers=args.worker, gpus=gpus)
         out_path = args.output_path or args.out

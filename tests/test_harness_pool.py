@@ -75,3 +75,33 @@ def test_pool_of_spawned_workers_two_workers_two_gpus(tmp_path):
     buf = io.StringIO()
     harness.dump_json(log, buf)
     assert '"ave_all_frame_bpp": 0.563000' in buf.getvalue()
+
+
+def test_force_intra_and_check_existing(tmp_path, monkeypatch):
+    """--force_intra: every frame an I frame (intra period 1, test_video.py:490-491); --check_existing: a point whose .bin and
+    .json exist with the right frame count is not coded again (test_video.py:130-137); the per-point log is written beside the
+    container (test_video.py:345-346); --save_decoded_frame hands run_one_point a reconstruction path."""
+    jobs = harness.jobs_from_config(GOLD["config"], dict(qp_i=[10], force_intra=True))
+    assert jobs and all(j["intra_period"] == 1 for j in jobs)
+    jobs = harness.jobs_from_config(GOLD["config"], dict(qp_i=[10], force_intra=True, force_intra_period=4))
+    assert all(j["intra_period"] == 4 for j in jobs)               # (the explicit period wins, like in the reference)
+    job = harness.jobs_from_config(GOLD["config"], dict(qp_i=[10]))[0]
+    calls = []
+
+    def fake_point(i_net, p_net, src, w, h, n, qp_i, qp_p, **kw):
+        calls.append(kw)
+        open(kw["bin_path"], "wb").write(b"bin")
+        return {"i_frame_num": 1, "p_frame_num": n - 1, "ave_all_frame_bpp": 0.25}
+
+    monkeypatch.setattr(harness, "run_one_point", fake_point)
+    opts = dict(stream_path=str(tmp_path), check_existing=True, save_decoded_frame=True)
+    first = harness.run_job(("i", "p"), job, opts)
+    folder = tmp_path / job["ds_name"]
+    assert (folder / f"{job['seq']}_q10.bin").exists() and json.load(open(folder / f"{job['seq']}_q10.json")) == first
+    assert calls[0]["rec_path"] == str(folder / f"{job['seq']}_q10.yuv") and calls[0]["bin_path"].endswith("_q10.bin")
+    again = harness.run_job(("i", "p"), job, opts)
+    assert again == first and len(calls) == 1                        # served from the stored log
+    harness.run_job(("i", "p"), dict(job, frame_num=job["frame_num"] + 1), opts)
+    assert len(calls) == 2                                           # a log with another frame count is not trusted
+    harness.run_job(("i", "p"), job, dict(opts, check_existing=False))
+    assert len(calls) == 3
