@@ -191,7 +191,12 @@ def test_manifest_run_two_workers_on_one_gpu_equals_one_worker(tmp_path, golden_
         sp = tmp_path / f"bins_w{w}"
         logs[w] = harness.run_config(config, dict(qp_i=[10, 50], stream_path=str(sp), reset_interval=3, record_gpu=True),
                                      workers=w, gpus=1)
-        sums[w] = {f: hashlib.sha256(open(os.path.join(sp, "S", f), "rb").read()).hexdigest() for f in sorted(os.listdir(sp / "S"))}
+        files = sorted(os.listdir(sp / "S"))
+        sums[w] = {f: hashlib.sha256(open(os.path.join(sp, "S", f), "rb").read()).hexdigest() for f in files if f.endswith(".bin")}
+        # every point's log beside its container, like the reference's worker writes it (test_video.py:345-346,367-368)
+        assert [f for f in files if f.endswith(".json")] == [f[:-4] + ".json" for f in sorted(sums[w])]
+        point = json.load(open(sp / "S" / "a_136x200.yuv_q10.json"))
+        assert point["i_frame_num"] + point["p_frame_num"] == N and "ave_all_frame_bpp" in point
     assert sorted(sums[1]) == ["a_136x200.yuv_q10.bin", "a_136x200.yuv_q50.bin", "b_136x200.yuv_q10.bin", "b_136x200.yuv_q50.bin"]
     assert sums[1] == sums[2]
     for seq in config["test_classes"]["S"]["sequences"]:
