@@ -102,10 +102,20 @@ def pin_rank_threads(local_rank, local_world):
     return cpus
 
 
+# tests/test_gpu_rccl_world1.py sets this to run the collectives below in a process group of ONE rank: the only way to put the
+# RCCL calls of the N > 1 path (init with a device id, fp32 broadcast, fp64 MAX all-reduce, all-gather, barrier) on real
+# hardware from a one-GPU box
+FORCE_COLLECTIVES = False
+
+
+def _alone(world):
+    return world == 1 and not FORCE_COLLECTIVES
+
+
 def broadcast_state_dict(model_name, sd, device, rank, world):
     """sd: {name: float32 ndarray} on rank 0 (ignored elsewhere).  Returns the same dict on every
     rank after ONE broadcast of a flat fp32 blob (20.7 M / 45.7 M parameters)."""
-    if world == 1:
+    if _alone(world):
         return sd
     import torch.distributed as dist
     spec = arch.spec_for(model_name).items
@@ -124,7 +134,7 @@ def broadcast_state_dict(model_name, sd, device, rank, world):
 
 
 def max_over_ranks(value, device, world):
-    if world == 1:
+    if _alone(world):
         return float(value)
     import torch.distributed as dist
     t = torch.tensor([value], device=device, dtype=torch.float64)
@@ -134,7 +144,7 @@ def max_over_ranks(value, device, world):
 
 def gather_over_ranks(value, device, world):
     """every rank's `value` (a float), as a list in rank order, on every rank"""
-    if world == 1:
+    if _alone(world):
         return [float(value)]
     import torch.distributed as dist
     mine = torch.tensor([value], device=device, dtype=torch.float64)
@@ -144,6 +154,6 @@ def gather_over_ranks(value, device, world):
 
 
 def barrier(world):
-    if world > 1:
+    if not _alone(world):
         import torch.distributed as dist
         dist.barrier()
