@@ -199,6 +199,24 @@ int dcvc_prior_dec_index(int dtype, int n_groups, int step, const void* scales, 
 int dcvc_prior_dec_restore(int dtype, int n_groups, int step, const int8_t* sym_chw,
                            const void* means, int64_t ldm, int H, int W, int C, const void* yhat_in,
                            int64_t ldhi, void* yhat_out, int64_t ldho, void* stream);
+/* DECODER hand-off with the kept entries compacted on the device (no reference counterpart: the reference gathers the kept
+ * indexes with a boolean mask, copies them with .cpu() and scatters the decoded symbols back, entropy_models.py:330-341 -
+ * same stream order; the round-3 path copied the whole index / symbol arrays, ~96 % sentinels).
+ *   dcvc_prior_dec_index_compact: as dcvc_prior_dec_index (idx_chw stays on the DEVICE), then the kept indexes in CHW order
+ *     are written by a kernel into idx_host[0 .. *count_host) and their number into *count_host - both dcvc_host_alloc
+ *     buffers (idx_host: one byte per position rounded up to 16), valid for the host once the stream has passed this point.
+ *   host: dcvc_rans_dec_decode_compact decodes exactly *count_host symbols into a pinned int8 buffer (16-byte aligned,
+ *     capacity as idx_host).
+ *   dcvc_prior_dec_restore_compact: fetches those symbols (coalesced 16-byte reads over the host link) and restores y_hat as
+ *     dcvc_prior_dec_restore does; idx_chw and workspace must be the ones of the step's index call.
+ * workspace: device, 16-byte aligned, dcvc_prior_dec_compact_ws_bytes(H, W, C, n_groups) bytes. */
+int64_t dcvc_prior_dec_compact_ws_bytes(int H, int W, int C, int n_groups);
+int dcvc_prior_dec_index_compact(int dtype, int n_groups, int step, const void* scales, int64_t lds_, int H, int W, int C,
+                                 float thres, uint8_t* idx_chw, void* workspace, uint8_t* idx_host,
+                                 int32_t* count_host, void* stream);
+int dcvc_prior_dec_restore_compact(int dtype, int n_groups, int step, const int8_t* sym_host, const uint8_t* idx_chw,
+                                   void* workspace, const void* means, int64_t ldm, int H, int W, int C,
+                                   const void* yhat_in, int64_t ldhi, void* yhat_out, int64_t ldho, void* stream);
 /* y_hat = y_hat * q   q_mode 0: max(qdec,0.5) per element; q_mode 1: sigmoid(qraw[p][1])*1.5+0.5
  * add_and_multiply (cuda_inference.py:48-55), common_model.py:246,294 */
 int dcvc_prior_finish(int dtype, int q_mode, void* yhat, int64_t ldh, const void* qsrc, int64_t ldq,
@@ -290,6 +308,10 @@ int64_t dcvc_rans_dec_get(dcvc_rans_dec*, int8_t* out, int64_t capacity);
  * calling thread, the second on its worker. */
 int dcvc_rans_dec_decode_and_get_y(dcvc_rans_dec*, const uint8_t* indexes, int64_t n, int group,
                                    int8_t* out);
+/* The compacted form of decode_and_get_y: `indexes` holds ONLY the kept entries (count of them, stream order, as
+ * dcvc_prior_dec_index_compact writes them); out[0..count) receives one int8 each.  Same coder split as above (the first
+ * coder takes floor(count / 2) symbols): the two forms consume a stream identically. */
+int dcvc_rans_dec_decode_compact(dcvc_rans_dec*, const uint8_t* indexes, int64_t count, int group, int8_t* out);
 /* Integrity check after the LAST symbol of a frame has been decoded (no reference counterpart: the reference decodes a
  * corrupt or truncated payload into garbage, rans.cpp:356-429): a rANS decoder that has undone every encoder step is back
  * in the encoder's initial state and has consumed every byte; returns 0, or -4 with dcvc_last_error() set. */

@@ -70,6 +70,9 @@ _SIGS = {
     "dcvc_prior_enc_step": (_I, [_I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _F, _P, _L, _P, _L, _P, _P]),
     "dcvc_prior_dec_index": (_I, [_I, _I, _I, _P, _L, _I, _I, _I, _F, _P, _P]),
     "dcvc_prior_dec_restore": (_I, [_I, _I, _I, _P, _P, _L, _I, _I, _I, _P, _L, _P, _L, _P]),
+    "dcvc_prior_dec_compact_ws_bytes": (_L, [_I, _I, _I, _I]),
+    "dcvc_prior_dec_index_compact": (_I, [_I, _I, _I, _P, _L, _I, _I, _I, _F, _P, _P, _P, _P, _P]),
+    "dcvc_prior_dec_restore_compact": (_I, [_I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _L, _P, _L, _P]),
     "dcvc_prior_finish": (_I, [_I, _I, _P, _L, _P, _L, _I, _I, _I, _P]),
     "dcvc_op_process_with_mask": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _L, _P]),
     "dcvc_op_combine_for_reading_2x": (_I, [_I, _P, _P, _P, _L, _P]),
@@ -107,6 +110,7 @@ _SIGS = {
     "dcvc_rans_dec_decode_z": (_I, [_P, _L, _I, _I, _I]),
     "dcvc_rans_dec_get": (_L, [_P, _P, _L]),
     "dcvc_rans_dec_decode_and_get_y": (_I, [_P, _P, _L, _I, _P]),
+    "dcvc_rans_dec_decode_compact": (_I, [_P, _P, _L, _I, _P]),
     "dcvc_rans_dec_check_end": (_I, [_P]),
     "dcvc_pmf_to_quantized_cdf": (_I, [_P, _I, _I, _P]),
     "dcvc_host_alloc": (_P, [c_size_t]),

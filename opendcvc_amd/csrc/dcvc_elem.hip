@@ -439,7 +439,7 @@ __global__ __launch_bounds__(EB) void prior_enc_kernel(PriorEncArgs a)
 
 template <typename T>
 __global__ __launch_bounds__(EB) void prior_dec_index_kernel(int n_groups, int step, const T* sc, int64_t lds, int H, int W,
-                                                            int C, float thres, uint8_t* idx_chw)
+                                                            int C, float thres, uint8_t* idx_chw, uint8_t* cnt16)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint8_t* sp = reinterpret_cast<uint8_t*>(smem);   // [Cg][PT]
@@ -457,6 +457,14 @@ __global__ __launch_bounds__(EB) void prior_dec_index_kernel(int n_groups, int s
         sp[cc * PT + pl] = keep ? dcvc_scale_to_index(scl, kScaleMin, kScaleMax, kLogScaleMin, kLogStepRecip) : (uint8_t)0xFF;
     }
     __syncthreads();
+    // kept entries of each (channel, 16-pixel run): what dec_compact_kernel scans (the compacted hand-off)
+    if (cnt16 != nullptr) {
+        for (int cc = threadIdx.x; cc < Cg; cc += EB) {
+            int c = 0;
+            for (int pl = 0; pl < PT; ++pl) c += (p0 + pl < HW && sp[cc * PT + pl] != 0xFF) ? 1 : 0;
+            cnt16[(int64_t)cc * gridDim.x + blockIdx.x] = (uint8_t)c;
+        }
+    }
     // The index array may live in pinned HOST memory (read in place by the host coder: no copy command).  A channel's PT = 16
     // pixels of this block are 16 contiguous bytes of the CHW array: one 16-byte store per channel where the rows are
     // aligned (H W a multiple of 16: 1080p, 4K), byte stores otherwise.
@@ -739,6 +747,146 @@ __global__ __launch_bounds__(CB) void compact_scatter_kernel(const int16_t* pack
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Decoder hand-off with the kept entries compacted on the device (round 4).  The index array of a checkerboard step is
+// ~96 % sentinels at the benchmarked rates: instead of copying all of it to the host (1 MB per step at 1080p, a copy
+// command) and all decoded symbols back, the kept table indexes are written IN STREAM ORDER (CHW order, the order of the
+// reference's boolean-mask compaction, entropy_models.py:330-341) into pinned host memory by a kernel, the host decodes
+// exactly that many symbols, and the restore step fetches them back with coalesced 16-byte reads and finds each position's
+// symbol by its rank.  Unit of the scan: one (channel, 16-pixel run) = 16 consecutive CHW positions; prior_dec_index_kernel
+// counts the kept entries of every run (cnt16), dec_compact_kernel turns them into offsets (off16) and writes the entries.
+__global__ __launch_bounds__(CB) void dec_compact_kernel(const uint8_t* idx_chw, const uint8_t* cnt16, int n16, int nblk, int64_t HW,
+                                                         uint8_t* out_host, int32_t* count_host, uint32_t* off16, int32_t* total_dev)
+{
+    const int b = blockIdx.x, nb = gridDim.x;
+    const int per = (n16 + nb - 1) / nb;
+    const int lo = min(b * per, n16), hi = min(lo + per, n16);
+    __shared__ int red[CB / 64];
+    __shared__ int wsum[CB / 64];
+    __shared__ int base_sh;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[CB * PT];
+    // entries kept by the runs in front of this block's (cnt16 is 4-byte aligned: whole words, then the tail)
+    int pre = 0;
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(cnt16);
+    const int nw = lo >> 2;
+    for (int i = threadIdx.x; i < nw; i += CB) {
+        const uint32_t v = cw[i];
+        pre += (int)((v & 0xFF) + ((v >> 8) & 0xFF) + ((v >> 16) & 0xFF) + (v >> 24));
+    }
+    if (threadIdx.x < (lo & 3)) pre += cnt16[(nw << 2) + threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_down(pre, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pre;
+    __syncthreads();
+    if (threadIdx.x == 0) base_sh = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    int base = base_sh;
+    const bool wide = (HW & (PT - 1)) == 0 && (reinterpret_cast<uintptr_t>(idx_chw) & 15) == 0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int r0 = lo; r0 < hi; r0 += CB) {
+        const int r = r0 + threadIdx.x;
+        const bool live = r < hi;
+        const int c = live ? cnt16[r] : 0;
+        // exclusive scan of c over the block: inside the wave by shuffles, across the four waves through LDS
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        __syncthreads();          // (stage / wsum of the previous round have been read)
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int off = inc - c;
+        for (int k = 0; k < w; ++k) off += wsum[k];
+        const int round_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (live) {
+            off16[r] = (uint32_t)(base + off);
+            if (c) {
+                const int cc = r / nblk, blk = r - cc * nblk;
+                const int64_t p0 = (int64_t)blk * PT;
+                const uint8_t* src = idx_chw + (int64_t)cc * HW + p0;
+                uint8_t v[PT];
+                if (wide) {
+                    *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(src);
+                } else {
+                    for (int j = 0; j < PT; ++j) v[j] = p0 + j < HW ? src[j] : (uint8_t)0xFF;
+                }
+                int o = off;
+#pragma unroll
+                for (int j = 0; j < PT; ++j)
+                    if (v[j] != 0xFF) stage[o++] = v[j];
+            }
+        }
+        __syncthreads();
+        // consecutive lanes write consecutive bytes of the pinned buffer: whole lines over the host link
+        for (int j = threadIdx.x; j < round_total; j += CB) out_host[base + j] = stage[j];
+        base += round_total;
+    }
+    if (b == nb - 1 && threadIdx.x == 0) {
+        *count_host = base;
+        *total_dev = base;
+    }
+}
+
+// the decoded symbols of the step (compacted, `*total` of them, written by the host coder into pinned memory) -> device
+__global__ void dec_gather_kernel(const uint4* src_host, uint4* dst, const int32_t* total_dev, int cap16)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n16 = (*total_dev + 15) >> 4;
+    if (i < n16 && i < cap16) dst[i] = src_host[i];
+}
+
+// prior_dec_restore_kernel on compacted symbols: the symbol of a kept position is csym[off16[run] + rank inside the run]
+template <typename T>
+__global__ __launch_bounds__(EB) void prior_dec_restore_compact_kernel(int n_groups, int step, const int8_t* csym,
+                                                                      const uint8_t* idx_chw, const uint32_t* off16,
+                                                                      const T* mu, int64_t ldm, int H, int W, int C,
+                                                                      const T* hin, int64_t ldhi, T* hout, int64_t ldho)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* bs = reinterpret_cast<uint32_t*>(smem);            // [Cg] offset of the run's first kept entry
+    uint32_t* mk = bs + C / n_groups;                            // [Cg] kept mask of the run's 16 positions
+    const int Cg = C / n_groups;
+    const int64_t HW = (int64_t)H * W;
+    const int64_t p0 = (int64_t)blockIdx.x * PT;
+    const bool wide = (HW & (PT - 1)) == 0 && (reinterpret_cast<uintptr_t>(idx_chw) & 15) == 0;
+    for (int cc = threadIdx.x; cc < Cg; cc += EB) {
+        const uint8_t* src = idx_chw + (int64_t)cc * HW + p0;
+        uint8_t v[PT];
+        if (wide) {
+            *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(src);
+        } else {
+            for (int j = 0; j < PT; ++j) v[j] = p0 + j < HW ? src[j] : (uint8_t)0xFF;
+        }
+        uint32_t m = 0;
+#pragma unroll
+        for (int j = 0; j < PT; ++j) m |= (uint32_t)(v[j] != 0xFF) << j;
+        mk[cc] = m;
+        bs[cc] = off16[(int64_t)cc * gridDim.x + blockIdx.x];
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < PT * Cg; it += EB) {
+        const int pl = it / Cg, cc = it - pl * Cg;
+        const int64_t p = p0 + pl;
+        if (p >= HW) continue;
+        const int h = (int)p / W, w = (int)p - h * W;
+        const int ga = active_group(n_groups, step, h, w);
+        const uint32_t m = mk[cc];
+        const float sym = (m >> pl) & 1u ? (float)csym[bs[cc] + __popc(m & ((1u << pl) - 1u))] : 0.f;
+        for (int g = 0; g < n_groups; ++g) {
+            const int ch = cc + g * Cg;
+            const float prev = step == 0 ? 0.f : ld(hin, p * ldhi + ch);
+            if (g != ga) {
+                st(hout, p * ldho + ch, prev);
+                continue;
+            }
+            const float yh = (float)to_t<T>(sym + ld(mu, p * ldm + ch));
+            st(hout, p * ldho + ch, step == 0 ? yh : prev + yh);
+        }
+    }
+}
+
 __global__ void copy_f32_kernel(float* dst, const float* src, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -898,7 +1046,7 @@ int dcvc_prior_dec_index(int dtype, int n_groups, int step, const void* scales, 
     return typed(dtype, [&](auto tag) {
         using T = decltype(tag);
         prior_dec_index_kernel<T><<<grid, EB, lds, (hipStream_t)stream>>>(n_groups,
-                                    step, (const T*)scales, lds_, H, W, C, thres, idx_chw);
+                                    step, (const T*)scales, lds_, H, W, C, thres, idx_chw, (uint8_t*)nullptr);
     });
 }
 
@@ -917,6 +1065,89 @@ int dcvc_prior_dec_restore(int dtype, int n_groups, int step, const int8_t* sym_
         prior_dec_restore_kernel<T><<<grid, EB, lds, (hipStream_t)stream>>>(n_groups,
                                     step, sym_chw, (const T*)means, ldm, H, W, C, (const T*)yhat_in, ldhi, (T*)yhat_out,
                                     ldho);
+    });
+}
+
+namespace {
+// workspace of the compacted decoder hand-off (device): [total: 16 bytes][off16: n16 x 4][cnt16: n16 -> 16][csym: n -> 16]
+struct DecWs {
+    int64_t n16, n, off_off16, off_cnt16, off_csym, bytes;
+    int nblk;
+};
+DecWs dec_ws(int H, int W, int C, int n_groups)
+{
+    DecWs w{};
+    const int64_t HW = (int64_t)H * W;
+    w.nblk = (int)((HW + PT - 1) / PT);
+    w.n16 = (int64_t)(C / n_groups) * w.nblk;
+    w.n = (int64_t)(C / n_groups) * HW;
+    w.off_off16 = 16;
+    w.off_cnt16 = w.off_off16 + w.n16 * 4;
+    w.off_csym = w.off_cnt16 + (w.n16 + 15) / 16 * 16;
+    w.bytes = w.off_csym + (w.n + 15) / 16 * 16;
+    return w;
+}
+}  // namespace
+
+int64_t dcvc_prior_dec_compact_ws_bytes(int H, int W, int C, int n_groups)
+{
+    if (H <= 0 || W <= 0 || C <= 0 || (n_groups != 2 && n_groups != 4) || C % n_groups) return 0;
+    return dec_ws(H, W, C, n_groups).bytes;
+}
+
+int dcvc_prior_dec_index_compact(int dtype, int n_groups, int step, const void* scales, int64_t lds_, int H, int W, int C,
+                                 float thres, uint8_t* idx_chw, void* workspace, uint8_t* idx_host, int32_t* count_host,
+                                 void* stream)
+{
+    DCVC_REQUIRE(scales && idx_chw && workspace && idx_host && count_host, "dcvc_prior_dec_index_compact: null pointer");
+    DCVC_REQUIRE((int64_t)H * W < (1ll << 31), "dcvc_prior_dec_index_compact: map too large");
+    DCVC_REQUIRE((n_groups == 2 || n_groups == 4) && step >= 0 && step < n_groups && C % n_groups == 0,
+                 "dcvc_prior_dec_index_compact: bad groups/step");
+    DCVC_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "dcvc_prior_dec_index_compact: workspace must be 16-byte aligned");
+    const DecWs w = dec_ws(H, W, C, n_groups);
+    DCVC_REQUIRE(w.n < (1ll << 31), "dcvc_prior_dec_index_compact: too many symbols");
+    char* ws = (char*)workspace;
+    uint8_t* cnt16 = (uint8_t*)(ws + w.off_cnt16);
+    uint8_t* out_dev = nullptr;
+    int32_t* count_dev = nullptr;
+    DCVC_HIP(hipHostGetDevicePointer((void**)&out_dev, idx_host, 0));
+    DCVC_HIP(hipHostGetDevicePointer((void**)&count_dev, count_host, 0));
+    const size_t lds = (size_t)(C / n_groups) * PT;
+    int rc = typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        prior_dec_index_kernel<T><<<w.nblk, EB, lds, (hipStream_t)stream>>>(n_groups,
+                                    step, (const T*)scales, lds_, H, W, C, thres, idx_chw, cnt16);
+    });
+    if (rc) return rc;
+    hipLaunchKernelGGL(dec_compact_kernel, dim3(DCVC_COMPACT_BLOCKS), dim3(CB), 0, (hipStream_t)stream, idx_chw, cnt16, (int)w.n16,
+                       w.nblk, (int64_t)H * W, out_dev, count_dev, (uint32_t*)(ws + w.off_off16), (int32_t*)ws);
+    DCVC_LAUNCH_CHECK();
+    return 0;
+}
+
+int dcvc_prior_dec_restore_compact(int dtype, int n_groups, int step, const int8_t* sym_host, const uint8_t* idx_chw,
+                                   void* workspace, const void* means, int64_t ldm, int H, int W, int C,
+                                   const void* yhat_in, int64_t ldhi, void* yhat_out, int64_t ldho, void* stream)
+{
+    DCVC_REQUIRE(sym_host && idx_chw && workspace && means && yhat_out, "dcvc_prior_dec_restore_compact: null pointer");
+    DCVC_REQUIRE((int64_t)H * W < (1ll << 31), "dcvc_prior_dec_restore_compact: map too large");
+    DCVC_REQUIRE((n_groups == 2 || n_groups == 4) && step >= 0 && step < n_groups && C % n_groups == 0,
+                 "dcvc_prior_dec_restore_compact: bad groups/step");
+    DCVC_REQUIRE(step == 0 || yhat_in, "dcvc_prior_dec_restore_compact: yhat_in required after step 0");
+    const DecWs w = dec_ws(H, W, C, n_groups);
+    char* ws = (char*)workspace;
+    const int8_t* src_dev = nullptr;
+    DCVC_HIP(hipHostGetDevicePointer((void**)&src_dev, (void*)sym_host, 0));
+    DCVC_REQUIRE((reinterpret_cast<uintptr_t>(src_dev) & 15) == 0, "dcvc_prior_dec_restore_compact: symbol buffer must be 16-byte aligned");
+    const int cap16 = (int)((w.n + 15) / 16);
+    hipLaunchKernelGGL(dec_gather_kernel, dim3((cap16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const uint4*)src_dev,
+                       (uint4*)(ws + w.off_csym), (const int32_t*)ws, cap16);
+    const size_t lds = (size_t)(C / n_groups) * 8;
+    return typed(dtype, [&](auto tag) {
+        using T = decltype(tag);
+        prior_dec_restore_compact_kernel<T><<<w.nblk, EB, lds, (hipStream_t)stream>>>(n_groups, step,
+                                    (const int8_t*)(ws + w.off_csym), idx_chw, (const uint32_t*)(ws + w.off_off16),
+                                    (const T*)means, ldm, H, W, C, (const T*)yhat_in, ldhi, (T*)yhat_out, ldho);
     });
 }
 

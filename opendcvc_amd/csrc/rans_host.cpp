@@ -547,6 +547,18 @@ struct DecHalf {
         close(c);
     }
 
+    // y symbols whose table indexes arrive already compacted (dcvc_prior_dec_index_compact): entries [a, b) of `idx`, one
+    // symbol each, no sentinels to skip and nothing to zero-fill
+    void decode_packed(const CdfGroup& g, const uint8_t* idx, int8_t* out, int64_t a, int64_t b)
+    {
+        if (b <= a) return;
+        const DecTable* tab = g.dtab.data();
+        DecCursor c = open();
+        for (int64_t i = a; i < b; ++i) out[i] = (int8_t)c.decode(tab[idx[i]]);
+        decoded += b - a;
+        close(c);
+    }
+
     // z symbols: `cnt` values, `per_channel` consecutive ones share table start, start + 1, ...
     void decode_channels(const CdfGroup& g, int8_t* out, int64_t cnt, int start, int per_channel)
     {
@@ -820,6 +832,29 @@ int dcvc_rans_dec_decode_and_get_y(dcvc_rans_dec* d, const uint8_t* indexes, int
     d->worker[1].wait_idle();
     if (d->half[0].overrun || (d->two && d->half[1].overrun)) {
         dcvc::set_error("dcvc_rans_dec_decode_and_get_y: bit stream exhausted (corrupt or truncated stream)");
+        return dcvc::E_STREAM;
+    }
+    return 0;
+}
+
+int dcvc_rans_dec_decode_compact(dcvc_rans_dec* d, const uint8_t* indexes, int64_t count, int group, int8_t* out)
+{
+    DCVC_REQUIRE(d && ((indexes && out) || count == 0) && count >= 0, "dcvc_rans_dec_decode_compact: bad arguments");
+    DCVC_REQUIRE(group >= 0 && group < (int)d->groups.size(), "dcvc_rans_dec_decode_compact: unknown cdf group %d", group);
+    d->worker[0].wait_idle();
+    d->worker[1].wait_idle();
+    d->out.clear();
+    const CdfGroup* g = &d->groups[group];
+    int mx = 0;
+    for (int64_t i = 0; i < count; ++i) mx = indexes[i] > mx ? indexes[i] : mx;
+    DCVC_REQUIRE(mx < g->n, "dcvc_rans_dec_decode_compact: cdf index %d out of range (%d tables)", mx, g->n);
+    // the same split as dec_run_y: the first coder takes floor(count / 2) symbols, the second the rest
+    const int64_t k0 = d->two ? count / 2 : count;
+    if (d->two) d->worker[1].post([=] { d->half[1].decode_packed(*g, indexes, out, k0, count); });
+    d->half[0].decode_packed(*g, indexes, out, 0, k0);
+    d->worker[1].wait_idle();
+    if (d->half[0].overrun || (d->two && d->half[1].overrun)) {
+        dcvc::set_error("dcvc_rans_dec_decode_compact: bit stream exhausted (corrupt or truncated stream)");
         return dcvc::E_STREAM;
     }
     return 0;

@@ -219,6 +219,16 @@ class EntropyCoder:
         back in its initial state / has bytes left over).  No reference counterpart (it decodes garbage silently)."""
         check(_lib.lib().dcvc_rans_dec_check_end(self.dec), "corrupt or truncated frame payload")
 
+    def decode_compact(self, indexes, count, cdf_group_index, out):
+        """Synchronous: `indexes[:count]` are the KEPT table indexes only (compacted on the device, stream order); decodes one
+        symbol each into out[:count]."""
+        if indexes.dtype != np.uint8 or out.dtype != np.int8 or count < 0 or indexes.size < count or out.size < count or \
+                not indexes.flags.c_contiguous or not out.flags.c_contiguous:
+            raise DcvcError("decode_compact: need contiguous uint8 indexes and an int8 output of at least `count` entries")
+        check(_lib.lib().dcvc_rans_dec_decode_compact(self.dec, _ip(indexes), int(count), cdf_group_index, _ip(out)),
+              "decode_compact")
+        return count
+
     def decode_and_get_y(self, indexes, cdf_group_index, out):
         """Synchronous: decodes straight from `indexes` into `out` (both host arrays of the same length)."""
         if indexes.dtype != np.uint8 or out.dtype != np.int8 or out.size < indexes.size or \

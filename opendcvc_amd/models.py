@@ -139,6 +139,19 @@ class _ModelScope:
         self.m._owner.release()
 
 
+# DCVC_DEC_COMPACT=0: the decoder hands whole index / symbol arrays over by copy commands (round 3's path; A/B measurements)
+DEC_COMPACT = os.environ.get("DCVC_DEC_COMPACT", "1") != "0"
+
+
+class _CompactStep:
+    """one checkerboard decoding step's hand-off in the compacted form: pinned kept-index / count buffers, the device-side
+    index array and workspace the restore needs again, later the pinned decoded symbols"""
+    __slots__ = ("buf", "cnt", "idx", "ws", "cap", "sym")
+
+    def __init__(self, buf, cnt, idx, ws, cap):
+        self.buf, self.cnt, self.idx, self.ws, self.cap, self.sym = buf, cnt, idx, ws, cap, None
+
+
 # DCVC_NO_FORK=1: no second stream inside a run (the temporal prior encoder then runs behind the hyper decoder)
 _FORK = os.environ.get("DCVC_NO_FORK") != "1"
 _PICTURE_RING = os.environ.get("DCVC_PICTURE_RING") == "1"
@@ -454,13 +467,27 @@ class CompressionModel(tnn.Module):
     # one checkerboard decoding step = three pieces, so that the device pieces can sit inside captured runs
     # (device index build -> host rANS decode -> device restore)
     def _index_to_host(self, groups, step, scales, H, W, C, key):
-        """device: cdf indexes of the step's symbols -> pinned host buffer (stream-ordered copy).
+        """device: cdf indexes of the step's symbols -> host.  Default (DEC_COMPACT): the KEPT indexes only, compacted in stream
+        order by a kernel that writes them (and their count) straight into pinned buffers - returns a _CompactStep; the
+        decoded symbols come back the same way (_symbols_to_device).  DCVC_DEC_COMPACT=0: the whole array, see below.
+
+        Whole-array form: pinned host buffer by a stream-ordered copy.
         Measured in round 4 (profiles/r04_dec_inplace.txt): the kernel writing the indexes straight into the pinned buffer takes
         39 us instead of 5.4 us + a ~10 us copy command, and the restore kernel reading the symbols in place 108 us instead
         of 7.7 us + copy - a channel's run of 16 pixels is 16 bytes, one bus transaction per lane, where the copy moves
         whole lines; only z (read coalesced, 65 KB) is taken in place."""
         n = (C // groups) * H * W
         idx = torch.empty(n, dtype=torch.uint8, device=scales.device)
+        if DEC_COMPACT:
+            lib = _lib.lib()
+            cap = (n + 15) // 16 * 16
+            ws = torch.empty(int(lib.dcvc_prior_dec_compact_ws_bytes(H, W, C, groups)), dtype=torch.uint8, device=scales.device)
+            buf = self.entropy_coder.pinned(key + "_cidx", cap)
+            cnt = self.entropy_coder.pinned(key + "_ccnt", 16)
+            check(lib.dcvc_prior_dec_index_compact(L.dtype_code(scales.dtype), groups, step, L._p(scales), scales.stride(1),
+                                                   H, W, C, self._thres(), L._p(idx), L._p(ws), ctypes.c_void_p(buf.ptr),
+                                                   ctypes.c_void_p(cnt.ptr), self._stream()), "prior_dec_index_compact")
+            return _CompactStep(buf, cnt, idx, ws, cap)
         check(_lib.lib().dcvc_prior_dec_index(L.dtype_code(scales.dtype), groups, step, L._p(scales), scales.stride(1),
                                               H, W, C, self._thres(), L._p(idx), self._stream()), "prior_dec_index")
         buf = self.entropy_coder.pinned(key + "_idx", n)
@@ -468,7 +495,15 @@ class CompressionModel(tnn.Module):
         return buf
 
     def _decode_on_host(self, idx_host, n, key):
-        """host: rANS-decode n symbols (the caller has waited for the index copy)"""
+        """host: rANS-decode the step's symbols (the caller has waited for the stream to pass the index hand-off)"""
+        if isinstance(idx_host, _CompactStep):
+            cs = idx_host
+            count = int(cs.cnt.view(np.int32, 1)[0])
+            if not 0 <= count <= n:
+                raise DcvcError("decoder hand-off: %d kept symbols of %d positions" % (count, n))
+            cs.sym = self.entropy_coder.pinned(key + "_csym", cs.cap)
+            self.entropy_coder.decode_compact(cs.buf.view(np.uint8, cs.cap), count, self._g_group, cs.sym.view(np.int8, cs.cap))
+            return cs
         sb = self.entropy_coder.pinned(key + "_sym", n)
         self.entropy_coder.decode_and_get_y(idx_host.view(np.uint8, n), self._g_group, sb.view(np.int8, n))
         return sb
@@ -477,6 +512,13 @@ class CompressionModel(tnn.Module):
         """device: upload the decoded symbols (stream-ordered copy, see _index_to_host) and restore y_hat at the step's
         positions"""
         out = yhat if out is None else out
+        if isinstance(sym_host, _CompactStep):
+            cs = sym_host
+            check(_lib.lib().dcvc_prior_dec_restore_compact(
+                L.dtype_code(means.dtype), groups, step, ctypes.c_void_p(cs.sym.ptr), L._p(cs.idx), L._p(cs.ws), L._p(means),
+                means.stride(1), H, W, C, L._p(yhat), yhat.stride(1), L._p(out), out.stride(1), self._stream()),
+                "prior_dec_restore_compact")
+            return
         sym = torch.empty(n, dtype=torch.int8, device=yhat.device)
         check(_lib.lib().dcvc_memcpy_h2d(L._p(sym), ctypes.c_void_p(sym_host.ptr), n, self._stream()), "h2d")
         check(_lib.lib().dcvc_prior_dec_restore(L.dtype_code(means.dtype), groups, step, L._p(sym), L._p(means),

@@ -188,3 +188,61 @@ def test_compact_symbols_writes_kept_entries_in_order_to_pinned_memory(parts, n)
         assert kept[p] == want.size
         assert np.array_equal(got[p, :want.size], want)
         assert np.all(got[p, want.size:].view(np.uint8) == 0xAB)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("groups,H,W,C,thres", [(2, 68, 120, 256, 0.12), (2, 17, 30, 256, 0.12), (4, 9, 13, 64, 0.12), (4, 68, 120, 256, 0.3),
+                                                (2, 136, 240, 256, 0.12), (2, 20, 24, 128, -1.0), (2, 12, 16, 64, 100.0)])
+def test_decoder_hand_off_compacted_on_the_device(dtype, groups, H, W, C, thres):
+    """dcvc_prior_dec_index_compact / dcvc_prior_dec_restore_compact (the decoder's hand-off with the kept entries compacted on
+    the device; same stream order as the reference's boolean-mask gather, entropy_models.py:330-341) against the whole-array
+    entry points: the pinned buffer holds exactly the non-sentinel indexes of dcvc_prior_dec_index in CHW order and their
+    count, nothing behind them is touched, and the restore from compacted symbols equals dcvc_prior_dec_restore from the
+    scattered array bit for bit.  Cases: HW a multiple of 16 and not, every step of both group counts, several scan rounds per
+    block (136x240), everything kept (thres < 0), nothing kept."""
+    import ctypes
+    from opendcvc_amd import _lib, entropy, nn
+    lib = _lib.lib()
+    rng = np.random.default_rng(H * W + C + groups)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dt = nn.dtype_code(dtype)
+    n = (C // groups) * H * W
+    cap = (n + 15) // 16 * 16
+    scales = torch.from_numpy(np.exp(rng.normal(-2.4, 1.0, (H, W, C))).astype(np.float32)).to(dtype).cuda()
+    means = torch.from_numpy(rng.normal(0, 2, (H, W, C)).astype(np.float32)).to(dtype).cuda()
+    prev = torch.from_numpy(rng.normal(0, 2, (H, W, C)).astype(np.float32)).to(dtype).cuda()
+    ws_bytes = int(lib.dcvc_prior_dec_compact_ws_bytes(H, W, C, groups))
+    assert ws_bytes > cap
+    for step in range(groups):
+        full = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.dcvc_prior_dec_index(dt, groups, step, nn._p(scales), scales.stride(1), H, W, C, thres, nn._p(full), st), "index")
+        idx = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+        ws = torch.zeros(ws_bytes, dtype=torch.uint8, device="cuda")
+        hidx, hcnt, hsym = entropy.PinnedBuffer(cap), entropy.PinnedBuffer(16), entropy.PinnedBuffer(cap)
+        hidx.u8[:] = 0xAB
+        _lib.check(lib.dcvc_prior_dec_index_compact(dt, groups, step, nn._p(scales), scales.stride(1), H, W, C, thres, nn._p(idx),
+                                                    nn._p(ws), ctypes.c_void_p(hidx.ptr), ctypes.c_void_p(hcnt.ptr), st), "index_compact")
+        torch.cuda.synchronize()
+        f = full.cpu().numpy()
+        assert np.array_equal(idx.cpu().numpy(), f)
+        keep = f != 0xFF
+        count = int(hcnt.view(np.int32, 1)[0])
+        assert count == int(keep.sum())
+        if thres < 0:
+            assert count == n
+        assert np.array_equal(hidx.u8[:count], f[keep]) and np.all(hidx.u8[count:] == 0xAB)
+        sym_full = np.where(keep, rng.integers(-128, 128, n), 0).astype(np.int8)
+        hsym.u8[:] = 0x55
+        hsym.view(np.int8, cap)[:count] = sym_full[keep]
+        want = torch.empty((H, W, C), dtype=dtype, device="cuda")
+        got = torch.empty((H, W, C), dtype=dtype, device="cuda")
+        sym_dev = torch.from_numpy(sym_full).cuda()
+        yin = prev if step else None
+        _lib.check(lib.dcvc_prior_dec_restore(dt, groups, step, nn._p(sym_dev), nn._p(means), means.stride(1), H, W, C,
+                                              nn._p(yin) if step else None, prev.stride(1), nn._p(want), want.stride(1), st), "restore")
+        _lib.check(lib.dcvc_prior_dec_restore_compact(dt, groups, step, ctypes.c_void_p(hsym.ptr), nn._p(idx), nn._p(ws), nn._p(means),
+                                                      means.stride(1), H, W, C, nn._p(yin) if step else None, prev.stride(1),
+                                                      nn._p(got), got.stride(1), st), "restore_compact")
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        prev = want

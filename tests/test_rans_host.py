@@ -99,6 +99,51 @@ def test_sentinel_equals_compaction_and_roundtrips(two):
     assert np.array_equal(out[keep], sym[keep].astype(np.int8)) and not np.any(out[~keep])
 
 
+@pytest.mark.parametrize("two", [0, 1])
+@pytest.mark.parametrize("kept_frac", [0.0, 0.04, 0.5, 1.0])
+def test_compact_decode_equals_sentinel_decode(two, kept_frac):
+    """dcvc_rans_dec_decode_compact (kept indexes only, as the device compaction hands them over) consumes a stream exactly
+    like decode_and_get_y on the sentinel array: same symbols, same coder split, same end state - over two consecutive
+    calls on one stream (the two checkerboard steps of a frame) and for 0 / 1 / odd counts."""
+    from opendcvc_amd.entropy import EntropyCoder
+    g = O.gaussian_tables()
+    rng = np.random.default_rng(17 + two)
+    steps = []
+    for n in (3, 30011, 1, 8193):
+        idx = rng.integers(0, 128, n).astype(np.uint8)
+        sigma = 0.11 * (16 / 0.11) ** (idx / 127.0)
+        sym = np.clip(np.round(rng.standard_normal(n) * sigma), -128, 127).astype(np.int16)
+        keep = rng.random(n) < (1.0 if n == 3 else kept_frac)        # (the first step keeps all: the stream is never empty)
+        steps.append((np.where(keep, idx, 0xFF).astype(np.uint8), keep, sym))
+    c = EntropyCoder()
+    c.add_cdf(*g)
+    c.set_use_two_entropy_coders(bool(two))
+    c.reset()
+    for full, keep, sym in steps:
+        c.encode_y(((sym.astype(np.int32) * 256 + full) & 0xFFFF).astype(np.uint16).view(np.int16), 0)
+    c.flush()
+    stream = c.get_encoded_stream()
+    c.set_stream(stream)
+    want = []
+    for full, keep, sym in steps:
+        out = np.empty(full.size, np.int8)
+        c.decode_and_get_y(full, 0, out)
+        want.append(out)
+    c.check_end()
+    c.set_stream(stream)
+    for (full, keep, sym), w in zip(steps, want):
+        cidx = np.concatenate([full[keep], np.full(5, 0xAB, np.uint8)])      # (entries behind `count` are never looked at)
+        out = np.full(cidx.size, 77, np.int8)
+        assert c.decode_compact(cidx, int(keep.sum()), 0, out) == int(keep.sum())
+        assert np.array_equal(out[:int(keep.sum())], w[keep]) and np.all(out[int(keep.sum()):] == 77)
+        assert np.array_equal(w[keep], sym[keep].astype(np.int8))
+    c.check_end()
+    with pytest.raises(_lib.DcvcError):
+        c.decode_compact(np.zeros(3, np.uint8), 4, 0, np.zeros(8, np.int8))          # count beyond the array
+    with pytest.raises(_lib.DcvcError):
+        c.decode_compact(np.full(3, 200, np.uint8), 3, 0, np.zeros(8, np.int8))      # table index out of range
+
+
 def test_pmf_to_quantized_cdf(kat):
     from opendcvc_amd.entropy import pmf_to_quantized_cdf
     for p, c, n in zip(kat["pmf_in"], kat["pmf_out"], kat["pmf_len"]):
