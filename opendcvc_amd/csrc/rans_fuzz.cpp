@@ -31,6 +31,7 @@ struct Rng {      // xorshift64*: deterministic, no library state
 };
 
 int g_fail = 0;
+static int g_compact_turn = 0;       // every other frame decodes its second half in the compacted form
 #define EXPECT(cond, ...)                     \
     do {                                      \
         if (!(cond)) {                        \
@@ -161,6 +162,17 @@ int decode(dcvc_rans_dec* d, const std::vector<uint8_t>& s, const Frame& f, int 
             EXPECT(rc == 0, "decode_y rc %d", rc);
             const int64_t g2 = dcvc_rans_dec_get(d, out.data(), (int64_t)n);
             rc = g2 < 0 ? (int)g2 : 0;
+        } else if (g_compact_turn ^= 1) {
+            // the compacted form of the same call (what the device hand-off of DMC / DMCI.decompress uses): kept indexes only, in
+            // exact-size heap blocks, scattered back here for the comparison below
+            std::vector<uint8_t> cidx;
+            for (size_t i = 0; i < n; ++i)
+                if (idx[i] != 0xFF) cidx.push_back(idx[i]);
+            cidx.shrink_to_fit();
+            std::vector<int8_t> co(cidx.size());
+            rc = dcvc_rans_dec_decode_compact(d, cidx.data(), (int64_t)cidx.size(), yg, co.data());
+            size_t k = 0;
+            for (size_t i = 0; i < n; ++i) out[i] = idx[i] != 0xFF ? co[k++] : (int8_t)0;
         } else {
             rc = dcvc_rans_dec_decode_and_get_y(d, idx.data(), (int64_t)n, yg, out.data());
         }

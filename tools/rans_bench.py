@@ -30,6 +30,8 @@ def tm(label, f, *a):
 
 
 out0 = np.empty(n, np.int8); out1 = np.empty(n, np.int8); zo = np.empty(z.size, np.int8)
+c0, c1 = np.ascontiguousarray(i0[i0 != 0xff]), np.ascontiguousarray(i1[i1 != 0xff])
+co0, co1 = np.empty(c0.size, np.int8), np.empty(c1.size, np.int8)
 for r in range(reps):
     tm("enc.reset", ec.reset)
     tm("enc.encode_z", ec.encode_z, z, int(zg), int(zoff), int(zper))
@@ -42,11 +44,17 @@ for r in range(reps):
     tm("dec.get_z", ec.get_decoded, zo)
     tm("dec.step0", ec.decode_and_get_y, i0, yg, out0)
     tm("dec.step1", ec.decode_and_get_y, i1, yg, out1)
+    # the same two steps in the compacted form (what DMC.decompress uses: the kept indexes only)
+    tm("dec.set_stream", ec.set_stream, s)
+    ec.decode_z(z.size, int(zg), int(zoff), int(zper)); ec.get_decoded(zo)
+    tm("dec.compact0", ec.decode_compact, c0, c0.size, yg, co0)
+    tm("dec.compact1", ec.decode_compact, c1, c1.size, yg, co1)
 assert np.array_equal(np.frombuffer(s, np.uint8), d["stream"]), "stream differs from the recorded one"
 assert np.array_equal(zo, z)
 for p, i, o in ((p0, i0, out0), (p1, i1, out1)):
     kept = (p & 0xff) != 0xff
     assert np.array_equal(kept, i != 0xff) and np.array_equal((p >> 8)[kept].astype(np.int8), o[kept]) and not o[~kept].any()
+assert np.array_equal(co0, out0[i0 != 0xff]) and np.array_equal(co1, out1[i1 != 0xff])
 kept0, kept1 = int(((p0 & 0xff) != 0xff).sum()), int(((p1 & 0xff) != 0xff).sum())
 print(f"kept symbols: step0 {kept0}  step1 {kept1}  of {n} each; z {z.size}; stream {len(s)} bytes")
 enc = dec = 0.0
