@@ -246,6 +246,38 @@ def test_graph_replay_equals_plain_launches():
         assert np.array_equal(x0, x1), f"frame {fi}: reconstruction differs"
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("two", [False, True])
+def test_compacted_decoder_hand_off_equals_whole_array_hand_off(dtype, two):
+    """The decoder with its hand-off compacted on the device (default) against the whole-array copies of round 3
+    (models.DEC_COMPACT = False, what DCVC_DEC_COMPACT=0 selects): the same pictures from the same packets, I frame (four
+    steps) and P frames (two steps), a map whose pixel count is not a multiple of 16 (80 x 112 -> 5 x 7 latents), one and two
+    coders."""
+    from opendcvc_amd import models
+    from opendcvc_amd.pipeline import SequenceDecoder, SequenceEncoder
+    h, w, n = 80, 112, 4
+    frames = [torch.from_numpy(weights.synthetic_frame_yuv444(h, w, fi, 9)).to("cuda", dtype) for fi in range(n)]
+    ie, pe = hip_codecs(1234, 0.12, dtype)
+    for m in (ie, pe):
+        m.set_use_two_entropy_coders(two)
+    enc = SequenceEncoder(ie, pe, 40, intra_period=-1, reset_interval=32)
+    pkts = [enc.encode(x) for x in frames]
+    outs = []
+    old = models.DEC_COMPACT
+    try:
+        for compact in (True, False):
+            models.DEC_COMPACT = compact
+            idc, pdc = hip_codecs(1234, 0.12, dtype)
+            dec = SequenceDecoder(idc, pdc, h, w, two)
+            outs.append([dec.decode(p).float().cpu().numpy() for p in pkts])
+            keys = [k for k in pdc.entropy_coder._pinned if isinstance(k[0], str)]
+            assert any(k[0].endswith("_cidx") for k in keys) == compact and any(k[0].endswith("_idx") for k in keys) == (not compact)
+    finally:
+        models.DEC_COMPACT = old
+    for fi, (a, b) in enumerate(zip(*outs)):
+        assert np.array_equal(a, b), f"frame {fi}: the two hand-off forms decode different pictures"
+
+
 @pytest.mark.parametrize("name", ["edge_q0", "edge_q63", "edge_nothres", "edge_allskip"])
 def test_fp32_edge_case_sequences_match_reference_records(golden_dir, name):
     """the same edge cases against the records the reference itself produced (sequences_edge.json)"""
