@@ -16,7 +16,8 @@ def calls(root):
     f = glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursive=True)[0]
     ours, other = {}, {}
     for r in csv.DictReader(open(f)):
-        (ours if "_GLOBAL__N_1" in r["Name"] else other)[r["Name"]] = int(r["Calls"])
+        mine = "_GLOBAL__N_1" in r["Name"] or "(anonymous namespace)" in r["Name"]      # (mangled or demangled: this library's kernels)
+        (ours if mine else other)[r["Name"]] = int(r["Calls"])
         TIMES[(root, r["Name"])] = float(r["TotalDurationNs"])
     return ours, other
 
@@ -25,7 +26,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--diff":
     (a, ao), (b, bo), n = calls(sys.argv[2]), calls(sys.argv[3]), int(sys.argv[4])
     d = {k: (b.get(k, 0) - a.get(k, 0)) / n for k in b}
     do = {k: (bo.get(k, 0) - ao.get(k, 0)) / n for k in bo}
-    print(f"own kernels per P-frame pair: {sum(d.values()):.1f}; torch / runtime kernels (copies, casts): {sum(do.values()):.1f}")
+    print(f"this library's kernel launches per P-frame pair: {sum(d.values()):.1f}; torch / runtime kernels (copy commands, casts): {sum(do.values()):.1f}")
     us = lambda k: (TIMES.get((sys.argv[3], k), 0.0) - TIMES.get((sys.argv[2], k), 0.0)) / n / 1e3
     tot = sum(us(k) for k in list(d) + list(do))
     is_copy = lambda k: "rocclr" in k
