@@ -586,29 +586,46 @@ def run_config(config, opts, workers=1, gpus=1):
     return merge_results(config, results)
 
 
-def main(argv=None):
+def _str2bool(v):
+    """the reference's str2bool (test_video.py:24-28): --flag 1 / true / yes / y / t"""
+    if isinstance(v, bool):
+        return v
+    if str(v).lower() in ("yes", "y", "true", "t", "1"):
+        return True
+    if str(v).lower() in ("no", "n", "false", "f", "0"):
+        return False
+    raise ValueError("boolean value expected, got %r" % (v,))
+
+
+def build_parser():
+    """The command line.  Every option of the reference's test_video.py (parse_args, test_video.py:30-56) is accepted under
+    its own spelling and value convention too (`--test_config`, `--model_path_i`, `--write_stream 1`, `--cuda_idx 0 1`, ...):
+    the command of the reference's README runs unchanged as `python -m opendcvc_amd.harness ...`."""
     import argparse
-    import torch
-    from . import weights
-    from .models import DMC, DMCI
     ap = argparse.ArgumentParser(description="DCVC-RT rate points of one YUV 4:2:0 sequence on the MI355X path")
-    ap.add_argument("--test-config", help="JSON dataset manifest (reference: dataset_config_example_yuv420.json): every "
+    flag = dict(nargs="?", const=True, default=False, type=_str2bool)       # `--flag` or the reference's `--flag True`
+    ap.add_argument("--test-config", "--test_config", help="JSON dataset manifest (reference: dataset_config_example_yuv420.json): every "
                     "sequence x rate point becomes a job on the worker pool (reference: test_video.py --test_config)")
     ap.add_argument("-w", "--worker", type=int, default=1, help="worker processes (may exceed --gpus)")
     ap.add_argument("--gpus", type=int, default=None, help="GPUs to spread the workers over (default: all visible)")
     ap.add_argument("--gpu-ids", type=lambda v: [t for t in v.split(",") if t], default=None,
                     help="physical device ids for the workers, comma separated (reference: --cuda_idx); default: the "
                          "parent's HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES list, else 0..gpus-1")
-    ap.add_argument("--force-root-path")
-    ap.add_argument("--force-frame-num", type=int, default=-1)
-    ap.add_argument("--force-intra-period", type=int, default=-1)
-    ap.add_argument("--stream-path", help="write every point's container to <stream-path>/<dataset>/<sequence>_q<qp>.bin")
-    ap.add_argument("--output-path", help="merged JSON log of the manifest run")
-    ap.add_argument("--calc-ssim", action="store_true", help="MS-SSIM per frame (reference --calc_ssim; host computation, slow)")
-    ap.add_argument("--force-intra", action="store_true", help="every frame an I frame (reference --force_intra)")
-    ap.add_argument("--check-existing", action="store_true",
+    ap.add_argument("--cuda_idx", type=int, nargs="+", default=None, help="the reference's spelling of --gpu-ids: 0 1 2 ...")
+    ap.add_argument("--cuda", **dict(flag, default=True), help="accepted for the reference's command line; there is no CPU path: "
+                    "--cuda 0 is an error")
+    ap.add_argument("--write_stream", "--write-stream", **flag, help="the reference's switch for writing the containers (to "
+                    "--stream_path, default out_bin); here giving --stream-path is enough")
+    ap.add_argument("--force-root-path", "--force_root_path")
+    ap.add_argument("--force-frame-num", "--force_frame_num", type=int, default=-1)
+    ap.add_argument("--force-intra-period", "--force_intra_period", type=int, default=-1)
+    ap.add_argument("--stream-path", "--stream_path", help="write every point's container to <stream-path>/<dataset>/<sequence>_q<qp>.bin")
+    ap.add_argument("--output-path", "--output_path", help="merged JSON log of the manifest run")
+    ap.add_argument("--calc-ssim", "--calc_ssim", **flag, help="MS-SSIM per frame (reference --calc_ssim; host computation, slow)")
+    ap.add_argument("--force-intra", "--force_intra", **flag, help="every frame an I frame (reference --force_intra)")
+    ap.add_argument("--check-existing", "--check_existing", **flag,
                     help="with --stream-path: do not code a point again whose .bin and .json exist (reference --check_existing)")
-    ap.add_argument("--save-decoded-frame", action="store_true",
+    ap.add_argument("--save-decoded-frame", "--save_decoded_frame", **flag,
                     help="with --stream-path: write the reconstruction beside the .bin (reference --save_decoded_frame)")
     ap.add_argument("--src-type", choices=("yuv420", "png"), default="yuv420",
                     help="--src is a planar 8-bit YUV 4:2:0 file, or a directory of im1.png ... / im00001.png ... (RGB)")
@@ -616,33 +633,50 @@ def main(argv=None):
     ap.add_argument("--width", type=int)
     ap.add_argument("--height", type=int)
     ap.add_argument("--frames", type=int)
-    ap.add_argument("--rate-num", type=int, default=4)
-    ap.add_argument("--qp-i", type=int, nargs="*")
-    ap.add_argument("--qp-p", type=int, nargs="*")
+    ap.add_argument("--rate-num", "--rate_num", type=int, default=4)
+    ap.add_argument("--qp-i", "--qp_i", type=int, nargs="*")
+    ap.add_argument("--qp-p", "--qp_p", type=int, nargs="*")
     ap.add_argument("--intra-period", type=int, default=-1)
-    ap.add_argument("--reset-interval", type=int, default=32)
-    ap.add_argument("--model-i", help="DMCI checkpoint (.pth.tar); synthetic weights if omitted")
-    ap.add_argument("--model-p", help="DMC checkpoint")
-    ap.add_argument("--force-zero-thres", type=float, default=0.12)
+    ap.add_argument("--reset-interval", "--reset_interval", type=int, default=32)
+    ap.add_argument("--model-i", "--model_path_i", help="DMCI checkpoint (.pth.tar); synthetic weights if omitted")
+    ap.add_argument("--model-p", "--model_path_p", help="DMC checkpoint")
+    ap.add_argument("--force-zero-thres", "--force_zero_thres", type=float, default=0.12)
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--bin-prefix", help="write <prefix>_q<qp>.bin")
     ap.add_argument("--out", help="JSON output path (default: stdout)")
     ap.add_argument("--verbose", type=int, default=1)
-    ap.add_argument("--verbose-json", action="store_true", help="per-frame lists in the log (reference --verbose_json)")
+    ap.add_argument("--verbose-json", "--verbose_json", **flag, help="per-frame lists in the log (reference --verbose_json)")
+    return ap
+
+
+def manifest_options(args, ap):
+    """(opts, gpus) of a manifest run from the parsed command line (both spellings)"""
+    if not args.cuda:
+        ap.error("--cuda 0: this framework has no CPU path (the reference's torch fallback is what oracle/ restates for the tests)")
+    gpu_ids = args.gpu_ids or ([str(i) for i in args.cuda_idx] if args.cuda_idx else None) or visible_gpu_ids()
+    gpus = args.gpus if args.gpus is not None else (len(gpu_ids) if gpu_ids else count_gpus())
+    if gpu_ids and gpus > len(gpu_ids):
+        ap.error("--gpus %d but only %d device ids are given / visible (%s)" % (gpus, len(gpu_ids), ",".join(gpu_ids)))
+    stream_path = args.stream_path or ("out_bin" if args.write_stream else None)      # (the reference's default folder)
+    opts = dict(gpu_ids=gpu_ids, rate_num=args.rate_num, qp_i=args.qp_i, qp_p=args.qp_p, force_root_path=args.force_root_path,
+                force_frame_num=args.force_frame_num, force_intra_period=args.force_intra_period,
+                reset_interval=args.reset_interval, model_i=args.model_i, model_p=args.model_p,
+                force_zero_thres=args.force_zero_thres, fp32=args.fp32, stream_path=stream_path,
+                verbose=args.verbose, verbose_json=args.verbose_json, calc_ssim=args.calc_ssim,
+                force_intra=args.force_intra, check_existing=args.check_existing, save_decoded_frame=args.save_decoded_frame)
+    return opts, gpus
+
+
+def main(argv=None):
+    import torch
+    from . import weights
+    from .models import DMC, DMCI
+    ap = build_parser()
     args = ap.parse_args(argv)
     if args.test_config:
         with open(args.test_config) as f:
             config = json.load(f)
-        gpu_ids = args.gpu_ids or visible_gpu_ids()
-        gpus = args.gpus if args.gpus is not None else (len(gpu_ids) if gpu_ids else count_gpus())
-        if gpu_ids and gpus > len(gpu_ids):
-            ap.error("--gpus %d but only %d device ids are given / visible (%s)" % (gpus, len(gpu_ids), ",".join(gpu_ids)))
-        opts = dict(gpu_ids=gpu_ids, rate_num=args.rate_num, qp_i=args.qp_i, qp_p=args.qp_p, force_root_path=args.force_root_path,
-                    force_frame_num=args.force_frame_num, force_intra_period=args.force_intra_period,
-                    reset_interval=args.reset_interval, model_i=args.model_i, model_p=args.model_p,
-                    force_zero_thres=args.force_zero_thres, fp32=args.fp32, stream_path=args.stream_path,
-                    verbose=args.verbose, verbose_json=args.verbose_json, calc_ssim=args.calc_ssim,
-                    force_intra=args.force_intra, check_existing=args.check_existing, save_decoded_frame=args.save_decoded_frame)
+        opts, gpus = manifest_options(args, ap)
         t0 = time.time()
         log = run_config(config, opts, workers=args.worker, gpus=gpus)
         out_path = args.output_path or args.out

@@ -105,3 +105,44 @@ def test_force_intra_and_check_existing(tmp_path, monkeypatch):
     assert len(calls) == 2                                           # a log with another frame count is not trusted
     harness.run_job(("i", "p"), job, dict(opts, check_existing=False))
     assert len(calls) == 3
+
+
+REFERENCE_README_COMMAND = ("--model_path_i ./checkpoints/cvpr2025_image.pth.tar --model_path_p ./checkpoints/cvpr2025_video.pth.tar "
+                            "--rate_num 4 --test_config ./dataset_config_example_yuv420.json --cuda 1 -w 1 --write_stream 1 "
+                            "--force_zero_thres 0.12 --output_path output.json --force_intra_period -1 --reset_interval 64 "
+                            "--force_frame_num -1 --check_existing 0 --verbose 0")
+
+
+def test_the_references_command_line_is_accepted_verbatim(monkeypatch):
+    """The argument list of the test command in the reference's README (README.md:166, parse_args test_video.py:30-56) parses
+    under the reference's own spellings and value conventions, and means the same: manifest, four rate points, one worker,
+    containers written (to the reference's default folder out_bin), reset interval 64, nothing re-used."""
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(harness, "count_gpus", lambda: 8)
+    ap = harness.build_parser()
+    a = ap.parse_args(REFERENCE_README_COMMAND.split())
+    opts, gpus = harness.manifest_options(a, ap)
+    assert a.test_config == "./dataset_config_example_yuv420.json" and a.worker == 1 and a.output_path == "output.json"
+    assert gpus == 8 and opts["gpu_ids"] is None
+    assert opts["model_i"].endswith("cvpr2025_image.pth.tar") and opts["model_p"].endswith("cvpr2025_video.pth.tar")
+    assert opts["rate_num"] == 4 and opts["reset_interval"] == 64 and opts["force_intra_period"] == -1 and opts["force_frame_num"] == -1
+    assert opts["stream_path"] == "out_bin" and opts["check_existing"] is False and opts["force_zero_thres"] == 0.12
+    assert opts["verbose"] == 0 and opts["calc_ssim"] is False and opts["force_intra"] is False
+    # every other option of the reference's parser, its spelling and its `--flag <bool>` convention
+    a = ap.parse_args("--test_config m.json --output_path o.json --cuda True --cuda_idx 4 5 -w 4 --qp_i 10 20 --qp_p 12 22 "
+                      "--force_intra true --calc_ssim 1 --save_decoded_frame yes --check_existing t --verbose_json True "
+                      "--stream_path bins --force_root_path /data --write_stream False".split())
+    opts, gpus = harness.manifest_options(a, ap)
+    assert opts["gpu_ids"] == ["4", "5"] and gpus == 2 and a.worker == 4
+    assert opts["qp_i"] == [10, 20] and opts["qp_p"] == [12, 22] and opts["force_root_path"] == "/data" and opts["stream_path"] == "bins"
+    assert all(opts[k] is True for k in ("force_intra", "calc_ssim", "save_decoded_frame", "check_existing", "verbose_json"))
+    # this repo's own spellings mean the same, flags without a value included
+    b = ap.parse_args("--test-config m.json --output-path o.json --gpu-ids 4,5 -w 4 --qp-i 10 20 --qp-p 12 22 --force-intra --calc-ssim "
+                      "--save-decoded-frame --check-existing --verbose-json --stream-path bins --force-root-path /data".split())
+    assert harness.manifest_options(b, ap) == (opts, gpus)
+    # no CPU path: the reference's --cuda 0 is refused, not silently run somewhere else
+    with pytest.raises(SystemExit):
+        harness.manifest_options(ap.parse_args("--test_config m.json --cuda 0".split()), ap)
+    with pytest.raises(SystemExit):
+        ap.parse_args("--test_config m.json --calc_ssim maybe".split())
