@@ -5,9 +5,12 @@
 // register ring): dcb_head128_kernel (the block's adaptor + first conv on large maps) and conv3x3_t128_kernel (3x3 stride-1
 // convs as pixel tile x output-channel slice).
 //
-// Why this form (measurements: tools/coissue_mb.hip, tools/mb/valu_rate_mb.hip):
-//   * Two waves of one SIMD do NOT overlap matrix and vector work (their times add), but ONE wave's instruction stream
-//     hides ~26 issue cycles of its own vector work behind every 32-cycle 32x32x16 MFMA.  So the gate g(u_lo) + g(u_hi)
+// Why this form (measurements: tools/coissue_mb.hip, tools/mb/coissue2_mb.hip, tools/mb/valu_rate_mb.hip):
+//   * A SIMD has ONE issue port for vector and matrix instructions (~8 cycles per MFMA, ~3.8 per plain vector instruction,
+//     ~8.5 per transcendental with two waves resident) beside the 32-cycle matrix pipe, and packed-fp32 vector instructions
+//     (v_pk_*_f32) additionally take the matrix pipe itself (docs/experiments.md, round 4; round 2 read its own
+//     micro-benchmark, whose vector wave hipcc had built from v_pk_fma_f32, as "two waves never overlap").  What a wave's
+//     stream hides behind each of its 32x32x16 MFMAs is ~26 issue cycles of vector work.  So the gate g(u_lo) + g(u_hi)
 //     of FFN chunk j is cut into pieces that are issued BETWEEN the MFMAs of W4 x v(j-1) and W3 x o -> u(j+1) of the same
 //     wave (two named u accumulator sets, one barrier per chunk, v chunks double-buffered in LDS).  hipcc left alone
 //     issues the gate as one block and sched_group_barrier pipelines of this length do not solve, so the kernel is written

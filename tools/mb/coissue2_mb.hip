@@ -23,7 +23,18 @@ template <int F, int KIND> __device__ __forceinline__ void vec(float (&u)[16], i
     for (int j = 0; j < F; ++j) {
         const int r = (slot * F + j) & 15;
         if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, 0.5" : "+v"(u[r]) : "v"(u[(r + 1) & 15]));
-        else {
+        else if (KIND >= 2) {
+            // two-register (64-bit) vector instructions: packed fp32 arithmetic, v_mov_b64; and other candidates of the tail's epilogues
+            const int r2 = r & 14;
+            double& d = reinterpret_cast<double&>(u[r2]);
+            const double& e = reinterpret_cast<const double&>(u[(r2 + 2) & 14]);
+            if (KIND == 2) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(d) : "v"(e));
+            if (KIND == 3) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(d) : "v"(e));
+            if (KIND == 4) asm volatile("v_mov_b64 %0, %1" : "+v"(d) : "v"(e));
+            if (KIND == 5) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(u[r]) : "v"(u[(r + 1) & 15]), "v"(u[(r + 2) & 15]));
+            if (KIND == 6) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "+v"(u[r]) : "v"(u[(r + 1) & 15]), "v"(u[(r + 2) & 15]));
+            if (KIND == 7) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(d) : "v"(e));
+        } else {
             switch (j & 3) {
             case 0: asm volatile("v_exp_f32 %0, %0" : "+v"(u[r])); break;
             case 1: asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(u[r])); break;
@@ -100,6 +111,11 @@ __global__ __launch_bounds__(512, 1) void kb(float* out, unsigned long long* cyc
     if ((threadIdx.x & 63) == 0) { cyc[(blockIdx.x * 8 + wave) * 2] = t0; cyc[(blockIdx.x * 8 + wave) * 2 + 1] = t1; }
 }
 
+static const char* kname(int k)
+{
+    static const char* n[] = {"fma ", "gate", "pk_fma_f32", "pk_add_f32", "mov_b64", "fma_mix", "cvt_pk_f16", "pk_mul_f32"};
+    return n[k];
+}
 static float* g_out;
 static unsigned long long* g_cyc;
 
@@ -141,7 +157,7 @@ void runa()
     }
     // ns per MFMA of one SIMD: 4 n MFMAs per wave, one or two waves per SIMD
     printf("A  F=%2d %s pad=%2d prio=%d : 1 wave/SIMD %6.1f us = %5.2f ns per MFMA | 2 waves/SIMD %6.1f us = %5.2f ns per MFMA  (ratio %.2f; ticks %.0f / %.0f)\n",
-           F, KIND ? "gate" : "fma ", Z, PRIO, us[0], us[0] * 1e3 / (4.0 * n), us[1], us[1] * 1e3 / (8.0 * n), us[1] / us[0], ticks[0], ticks[1]);
+           F, kname(KIND), Z, PRIO, us[0], us[0] * 1e3 / (4.0 * n), us[1], us[1] * 1e3 / (8.0 * n), us[1] / us[0], ticks[0], ticks[1]);
 }
 
 template <int Z, int KIND>
@@ -164,13 +180,31 @@ void runb(int n_vec)
         t[mode] = ms * 1e3f;
     }
     printf("B  MFMA wave pad=%2d, %s wave n=%d: MFMA alone %6.1f us, vector alone %6.1f us, both %6.1f us (sum %.1f, max %.1f)\n", Z,
-           KIND ? "gate" : "fma ", n_vec, t[0], t[1], t[2], t[0] + t[1], t[0] > t[1] ? t[0] : t[1]);
+           kname(KIND), n_vec, t[0], t[1], t[2], t[0] + t[1], t[0] > t[1] ? t[0] : t[1]);
 }
 
-int main()
+int main(int argc, char** argv)
 {
     (void)hipMalloc(&g_out, 256 * 512 * 4);
     (void)hipMalloc(&g_cyc, 256 * 16 * 8);
+    if (argc > 1) {     // second set: which vector instructions share the matrix pipe?
+        runb<0, 0>(1000);
+        runb<0, 2>(1000);
+        runb<0, 3>(1000);
+        runb<0, 7>(1000);
+        runb<0, 4>(1000);
+        runb<0, 5>(1000);
+        runb<0, 6>(1000);
+        runa<4, 0, 0>();
+        runa<4, 2, 0>();
+        runa<4, 3, 0>();
+        runa<4, 4, 0>();
+        runa<4, 5, 0>();
+        runa<4, 6, 0>();
+        runa<8, 2, 0>();
+        runa<8, 3, 0>();
+        return 0;
+    }
     runa<0, 0, 0>();
     runa<2, 0, 0>();
     runa<4, 0, 0>();
