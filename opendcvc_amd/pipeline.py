@@ -127,8 +127,11 @@ class EncodeDecodePipeline:
     coding overlaps the other stage's kernels.  (The reference runs the two loops one after the other,
     test_video.py:164-214 then :258-285; the frames, packets and reconstructions are the same.)"""
 
-    def __init__(self, encoder, decoder, device, depth=4):
+    def __init__(self, encoder, decoder, device, depth=None):
+        import os
         import torch
+        if depth is None:
+            depth = int(os.environ.get("DCVC_PIPE_DEPTH", "4"))
         self.encoder, self.decoder, self.device, self.depth = encoder, decoder, device, depth
         # (a high-priority decoder stream was measured: no difference - the pair is GPU-bound either way)
         self.enc_stream, self.dec_stream = torch.cuda.Stream(device), torch.cuda.Stream(device)
